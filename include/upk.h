@@ -1,0 +1,230 @@
+/*
+ * upk.h — C ABI of libupk.so, the MI355X (gfx950) kernel library under the
+ * UPGPT denoising hot path (UNetModel.forward x DDIMSampler loop -> VAE decode).
+ *
+ * The reference (soon-yau/upgpt) has NO native boundary: below its Python
+ * modules there is only torch.nn.functional.  Every entry
+ * point here therefore cites the reference *Python* call site whose ATen
+ * dispatch it replaces.  Bindings: upgpt_amd/_lib.py (ctypes); INTEGRATION.md
+ * shows the stub a reference maintainer would add.
+ *
+ * Rules of the ABI:
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers
+ *     unless the name says host;
+ *   - every launcher enqueues on the given hipStream_t, never synchronises,
+ *     never allocates (workspace is caller-provided through upk_set_workspace),
+ *     is safe to capture in a HIP graph, and returns 0 or a negative UPK_E*;
+ *   - no global mutable state outside upk_ctx.
+ *
+ * Activation layout: NHWC / token-major fp16 ([B, H*W, C] == [M, C] row major,
+ * leading dimension given in elements).  NCHW fp32 only at the public boundary
+ * (upk_nchw_f32_to_nhwc_f16, UPK_F_OUT_NCHW_F32).
+ */
+#ifndef UPK_H_
+#define UPK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UPK_VERSION 100 /* 0.1.0 */
+
+/* error codes */
+#define UPK_OK 0
+#define UPK_EINVAL (-1)     /* bad argument (null pointer, misaligned, negative size) */
+#define UPK_ESHAPE (-2)     /* shape not supported by any compiled kernel variant */
+#define UPK_EWORKSPACE (-3) /* split-K needs more workspace than was provided */
+#define UPK_EHIP (-4)       /* a HIP runtime call failed; see upk_last_error */
+#define UPK_ENODEV (-5)     /* no gfx950 device */
+
+typedef struct upk_ctx upk_ctx;
+typedef void* upk_stream; /* hipStream_t */
+
+int upk_version(void);
+/* Binds to HIP device `device` (hipSetDevice is NOT called by launchers; the
+ * caller keeps the device current). */
+int upk_create(upk_ctx** out, int device);
+int upk_destroy(upk_ctx* ctx);
+const char* upk_last_error(upk_ctx* ctx);
+/* Caller-owned scratch for split-K partial sums (fp32).  May be NULL/0. */
+int upk_set_workspace(upk_ctx* ctx, void* dptr, size_t bytes);
+/* Number of compute units of the bound device (256 on MI355X). */
+int upk_num_cus(upk_ctx* ctx);
+
+/* ------------------------------------------------------------------ */
+/* Weight packing (done once at load).                                  */
+/* ------------------------------------------------------------------ */
+/* Packed layout consumed by upk_conv2d_nhwc_f16 / upk_gemm_f16:
+ *   fp16 [K/32][n_pad][32], k = (ky*kw + kx) * cin_pad + ci,
+ *   cin_pad = round_up(cin, 32), n_pad = round_up(n_rows, 16), zero filled.
+ * `row_map` (device int32[n_rows_packed], may be NULL = identity) gives, for
+ * each packed row, the source output channel or -1 for a zero row: this is how
+ * head-dim padding (28->32 ...) and the GEGLU value/gate interleave are made.
+ * `col_map` (device int32[cin_packed], may be NULL) likewise maps packed input
+ * channels to source input channels (-1 = zero column).
+ * Source: fp32 OIHW conv weight (openaimodel.py:204,230,519,685; model.py) or
+ * fp32 [out,in] Linear weight (attention.py:161-168,40,60) with kh=kw=1. */
+int upk_pack_weight_f16(upk_ctx* ctx, const float* w_oihw, int cout, int cin, int kh, int kw,
+                        const int32_t* row_map, int n_rows_packed, const int32_t* col_map,
+                        int cin_packed, void* w_packed, upk_stream stream);
+/* bytes needed for the packed weight */
+size_t upk_packed_weight_bytes(int n_rows_packed, int cin_packed, int kh, int kw);
+
+/* ------------------------------------------------------------------ */
+/* Implicit-GEMM convolution / Linear (MFMA).                           */
+/* ------------------------------------------------------------------ */
+/* flags */
+#define UPK_F_SILU 0x1         /* y = silu(acc + bias ...) (openaimodel.py:509)            */
+#define UPK_F_GEGLU 0x2        /* y[:, j] = v * gelu_erf(g) (attention.py:42-44); weight    */
+                               /* rows packed as [32 value | 32 gate] per 64-row block       */
+#define UPK_F_OUT_F32 0x4      /* y is fp32 [M, ldy]                                         */
+#define UPK_F_OUT_NCHW_F32 0x8 /* y is fp32 NCHW [B, N, Ho, Wo] (public boundary)            */
+#define UPK_F_UPSAMPLE2X 0x10  /* input is nearest-2x upsampled on the fly                   */
+                               /* (openaimodel.py:116 + :107; model.py:53-56)                */
+#define UPK_F_PAD_ASYM 0x20    /* stride-2 conv with (0,1,0,1) padding (model.py:72-76)      */
+
+typedef struct upk_conv_desc {
+  /* input: up to two NHWC fp16 sources concatenated along C (openaimodel.py:736,
+   * ddpm.py:1568).  c1, c2 multiples of 32 (pad with zero channels); x2 may be NULL. */
+  const void* x1;
+  const void* x2;
+  int32_t c1, c2;
+  int32_t ld1, ld2; /* pixel stride in elements */
+  int32_t batch;
+  int32_t in_h, in_w; /* STORED spatial dims of the sources (before 2x upsample) */
+  int32_t ksize;      /* 1 or 3 */
+  int32_t stride;     /* 1 or 2 */
+  /* weights + epilogue */
+  const void* w_packed; /* upk_pack_weight_f16 layout, K = ksize^2 * (c1+c2) */
+  int32_t n_out;        /* valid output columns (GEGLU: packed rows = 2*n_out)     */
+  int32_t n_pad;        /* packed rows (multiple of 16)                            */
+  const float* bias;    /* [n_pad] fp32 in PACKED row order, or NULL               */
+  const void* residual; /* fp16 [M, ld_res] added after bias/act, or NULL          */
+  int32_t ld_res;
+  /* per-sample broadcast add (ResBlock emb_out, openaimodel.py:273):
+   * rowvec[(step * rv_step_stride) + b * rv_batch_stride + n], fp32. */
+  const float* rowvec;
+  int32_t rv_batch_stride;
+  int32_t rv_step_stride;
+  const int32_t* step; /* device scalar, NULL => 0 */
+  void* y;
+  int32_t ldy;
+  /* optional transposed tail: packed columns >= vt_from are written to
+   * vt[((b*vt_heads + h)*vt_dhead + d)*vt_ld + tok] (V^T for upk_attention_f16),
+   * with m = b*vt_tokens + tok, col - vt_from = h*vt_dhead + d.  vt==NULL: off. */
+  void* vt;
+  int32_t vt_from, vt_heads, vt_dhead, vt_ld, vt_tokens;
+  int32_t flags;
+} upk_conv_desc;
+
+/* Replaces F.conv2d (3x3 s1/s2 p1, 1x1) / F.linear call sites:
+ * ResBlock (openaimodel.py:255-275), Downsample (:158-160), Upsample (:109-119),
+ * SpatialTransformer.proj_in/out (attention.py:233-248), CrossAttention
+ * to_q/k/v/out (attention.py:161-168), GEGLU/FeedForward (attention.py:40,60),
+ * time_embed/emb_layers (openaimodel.py:506-511,220), VAE Decoder convs
+ * (model.py:462-568).  A Linear is ksize=1, batch=1, in_h=M, in_w=1. */
+int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream);
+
+/* Convenience wrapper: y[M,N] = act(A[M,K] @ W^T + bias) + residual. */
+int upk_gemm_f16(upk_ctx* ctx, const void* a, int lda, int m, int k, const void* w_packed,
+                 int n_out, int n_pad, const float* bias, const void* residual, int ld_res,
+                 void* y, int ldy, int flags, upk_stream stream);
+
+/* Forces a tile configuration / split-K factor for the next launches (tuning
+ * and tests). cfg < 0 and splitk <= 0 restore the heuristic. */
+int upk_conv_override(upk_ctx* ctx, int cfg, int splitk);
+/* Number of compiled tile configurations, and a description of one. */
+int upk_conv_num_configs(void);
+const char* upk_conv_config_name(int cfg);
+
+/* ------------------------------------------------------------------ */
+/* Fused attention: softmax(Q K^T * scale) V, online softmax, no n^2 tensor. */
+/* Replaces attention.py:178-192 (einsum/softmax/einsum) and model.py:180-196. */
+/* ------------------------------------------------------------------ */
+/* q  : fp16 [B, n_q , ldq ] head h at columns [h*d, (h+1)*d)
+ * k  : fp16 [B, n_kv, ldk ] same head layout, batch stride = k_batch_stride elements
+ * vt : fp16 [B, heads, d, vt_ld] (V transposed, vt_ld >= round_up(n_kv,32), zero padded)
+ * out: fp16 [B, n_q , ldo ]
+ * d in {32, 64, 128, 512} (head dims are padded to these by weight packing). */
+int upk_attention_f16(upk_ctx* ctx, const void* q, int ldq, long long q_batch_stride,
+                      const void* k, int ldk, long long k_batch_stride, const void* vt, int vt_ld,
+                      void* out, int ldo, long long o_batch_stride, int batch, int heads, int n_q,
+                      int n_kv, int d, float scale, upk_stream stream);
+
+/* ------------------------------------------------------------------ */
+/* Normalisation (wavefront reductions, fp32 statistics).               */
+/* ------------------------------------------------------------------ */
+/* GroupNorm over NHWC fp16, optional fused SiLU, input may be a 2-source
+ * channel concat; output is one [B*HW, c1+c2] fp16 tensor.
+ * Replaces GroupNorm32 (util.py:214-216, eps 1e-5), Normalize (attention.py:76-77
+ * and model.py:38-39, eps 1e-6) and the following SiLU/swish (openaimodel.py:203,227).
+ * stats_ws: fp32 scratch, >= upk_groupnorm_ws_bytes(batch, hw) bytes. */
+int upk_groupnorm_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* x2, int c2,
+                           int ld2, int batch, int hw, int groups, const float* gamma,
+                           const float* beta, float eps, int fuse_silu, void* y, int ldy,
+                           float* stats_ws, upk_stream stream);
+size_t upk_groupnorm_ws_bytes(int batch, int hw);
+
+/* LayerNorm over the last dim of fp16 [rows, d] (attention.py:203-205, eps 1e-5). */
+int upk_layernorm_f16(upk_ctx* ctx, const void* x, int ldx, int rows, int d, const float* gamma,
+                      const float* beta, float eps, void* y, int ldy, upk_stream stream);
+
+/* ------------------------------------------------------------------ */
+/* Small ops of the loop.                                               */
+/* ------------------------------------------------------------------ */
+/* timestep_embedding (util.py:151-171): out[i] = [cos(t_i f_j) | sin(t_i f_j)],
+ * f_j = exp(-ln(max_period) j / half), written as fp16 [n, ld_out] (cols >= dim zero). */
+int upk_timestep_embed_f16(upk_ctx* ctx, const float* t, int n, int dim, float max_period,
+                           void* out, int ld_out, upk_stream stream);
+
+/* NCHW fp32 -> NHWC fp16 with channel offset/padding: writes channels
+ * [c_off, c_off+c) of y[B, HW, ldy]; if zero_pad_to > c_off+c also zeroes the
+ * channels up to zero_pad_to (UNet stem input = cat[x, person_mask], ddpm.py:1568). */
+int upk_nchw_f32_to_nhwc_f16(upk_ctx* ctx, const float* x, int batch, int c, int hw, void* y,
+                             int ldy, int c_off, int zero_pad_to, float scale,
+                             upk_stream stream);
+int upk_nhwc_f16_to_nchw_f32(upk_ctx* ctx, const void* x, int ldx, int batch, int c, int hw,
+                             float* y, upk_stream stream);
+/* fp32 [rows, cols] -> fp16 [rows, ldy] (context tokens). */
+int upk_f32_to_f16(upk_ctx* ctx, const float* x, int rows, int cols, void* y, int ldy,
+                   upk_stream stream);
+
+/* One DDIM update (ddim.py:189-203), fp32 NCHW, n = B*C*H*W elements:
+ *   coef = coefs + 4 * (*step):  {sqrt(1-a_t), 1/sqrt(a_t), sqrt(a_prev), sqrt(1-a_prev-sigma^2)}
+ *   pred_x0 = (x - c0*e) * c1 ; x_prev = c2*pred_x0 + c3*e + noise_scaled
+ *   noise (may be NULL) = sigma_t * temperature * randn, [n_steps, n] indexed by *step.
+ * Also refreshes the UNet stem input: xin (fp16 NHWC [B, HW, ld_xin]) channels
+ * [0, C) = x_prev (the concat channels after them are static).  x is updated in place. */
+int upk_ddim_step_f32(upk_ctx* ctx, float* x, const float* eps, const float* coefs,
+                      const float* noise, const int32_t* step, float* pred_x0, void* xin,
+                      int ld_xin, int batch, int c, int hw, upk_stream stream);
+/* *step += 1 (end of a captured step graph). */
+int upk_advance_step(upk_ctx* ctx, int32_t* step, upk_stream stream);
+
+/* ------------------------------------------------------------------ */
+/* HIP graph helpers (the 50-step loop replays one captured step).      */
+/* ------------------------------------------------------------------ */
+typedef struct upk_graph upk_graph;
+int upk_graph_begin(upk_ctx* ctx, upk_stream stream);
+int upk_graph_end(upk_ctx* ctx, upk_stream stream, upk_graph** out);
+int upk_graph_launch(upk_ctx* ctx, upk_graph* g, upk_stream stream);
+int upk_graph_destroy(upk_ctx* ctx, upk_graph* g);
+
+/* ------------------------------------------------------------------ */
+/* Per-kernel-class timing with HIP events on the launch stream          */
+/* (bench.py roofline).  Classes: 0 igemm, 1 attention, 2 groupnorm,     */
+/* 3 layernorm, 4 other.                                                  */
+/* ------------------------------------------------------------------ */
+#define UPK_NUM_CLASSES 5
+int upk_prof_enable(upk_ctx* ctx, int on);
+/* Synchronises the recorded events and returns accumulated ms / launches
+ * per class since the last reset (host arrays of UPK_NUM_CLASSES). */
+int upk_prof_collect(upk_ctx* ctx, double* ms_host, long long* launches_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UPK_H_ */

@@ -1,0 +1,392 @@
+"""Op-level parity of the HIP kernels (through the C ABI) against plain PyTorch fp32
+references of the same op, fed the same fp16-rounded inputs."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from upgpt_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def nhwc16(x):  # NCHW fp32 -> NHWC fp16 contiguous
+    return x.permute(0, 2, 3, 1).contiguous().half()
+
+
+def conv_ref(x, w, b, stride=1, ups=False, asym=False):
+    x = x.half().float()
+    w = w.half().float()
+    if ups:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    if asym:
+        x = F.pad(x, (0, 1, 0, 1))
+        return F.conv2d(x, w, b, stride=2, padding=0)
+    return F.conv2d(x, w, b, stride=stride, padding=w.shape[-1] // 2)
+
+
+def make_desc(ctx, x1, w, bias, y, *, x2=None, stride=1, flags=0, n_out=None, residual=None, rowvec=None,
+              rv_bs=0, rv_ss=0, step=None, H=None, W=None, row_map=None, col_map=None):
+    B = x1.shape[0]
+    H = H or x1.shape[1]
+    W = W or x1.shape[2]
+    wp, n_pad = ctx.pack_weight(w.contiguous(), row_map=row_map, col_map=col_map)
+    d = L.ConvDesc()
+    d.x1 = x1.data_ptr(); d.c1 = x1.shape[-1]; d.ld1 = x1.shape[-1]
+    if x2 is not None:
+        d.x2 = x2.data_ptr(); d.c2 = x2.shape[-1]; d.ld2 = x2.shape[-1]
+    d.batch = B; d.in_h = H; d.in_w = W
+    d.ksize = w.shape[-1] if w.dim() == 4 else 1
+    d.stride = stride
+    d.w_packed = wp.data_ptr(); d.n_pad = n_pad
+    d.n_out = n_out if n_out is not None else w.shape[0]
+    bp = None
+    if bias is not None:
+        bp = torch.zeros(n_pad, device=DEV)
+        if row_map is not None:
+            m = row_map.long()
+            bp[: m.numel()] = torch.where(m >= 0, bias[m.clamp(min=0)], torch.zeros_like(bias[m.clamp(min=0)]))
+        else:
+            bp[: bias.numel()] = bias
+        d.bias = bp.data_ptr()
+    if residual is not None:
+        d.residual = residual.data_ptr(); d.ld_res = residual.shape[-1]
+    if rowvec is not None:
+        d.rowvec = rowvec.data_ptr(); d.rv_batch_stride = rv_bs; d.rv_step_stride = rv_ss
+    if step is not None:
+        d.step = step.data_ptr()
+    d.y = y.data_ptr(); d.ldy = y.shape[-1]
+    d.flags = flags
+    d._keep = (wp, bp)
+    return d
+
+
+def check(got, ref, tol=2e-2):
+    err = (got.float() - ref.float()).abs().max().item()
+    scale = ref.float().abs().max().item() + 1e-6
+    assert err / scale < tol, "max err %g vs scale %g" % (err, scale)
+
+
+@pytest.mark.parametrize("cin,cout,hw,stride,ups", [
+    (32, 224, (8, 6), 1, False), (224, 224, (32, 24), 1, False), (64, 96, (8, 8), 2, False),
+    (448, 448, (16, 12), 2, False), (96, 64, (4, 3), 1, True), (896, 896, (4, 3), 1, False),
+    (128, 16, (16, 16), 1, False),
+])
+def test_conv3x3(ctx, cin, cout, hw, stride, ups):
+    B = 2
+    H, W = hw
+    x = rnd(B, cin, H, W)
+    w = rnd(cout, cin, 3, 3, scale=1 / math.sqrt(9 * cin))
+    b = rnd(cout, scale=0.1)
+    ref = conv_ref(x, w, b, stride=stride, ups=ups)
+    Ho, Wo = ref.shape[2:]
+    y = torch.zeros(B, Ho, Wo, cout, device=DEV, dtype=torch.float16)
+    d = make_desc(ctx, nhwc16(x), w, b, y, stride=stride, flags=L.F_UPSAMPLE2X if ups else 0)
+    ctx.conv(d)
+    torch.cuda.synchronize()
+    check(y.permute(0, 3, 1, 2), ref)
+
+
+def test_conv_all_configs_and_splitk(ctx):
+    """Every compiled tile configuration and several split-K factors give the same answer."""
+    B, cin, cout, H, W = 2, 64, 224, 12, 10
+    x = rnd(B, cin, H, W)
+    w = rnd(cout, cin, 3, 3, scale=1 / math.sqrt(9 * cin))
+    b = rnd(cout, scale=0.1)
+    ref = conv_ref(x, w, b)
+    xn = nhwc16(x)
+    ncfg = ctx.lib.upk_conv_num_configs()
+    assert ncfg >= 8
+    try:
+        for cfg in range(ncfg):
+            for sk in (1, 2, 3):
+                y = torch.zeros(B, H, W, cout, device=DEV, dtype=torch.float16)
+                ctx.conv_override(cfg, sk)
+                ctx.conv(make_desc(ctx, xn, w, b, y))
+                torch.cuda.synchronize()
+                check(y.permute(0, 3, 1, 2), ref)
+    finally:
+        ctx.conv_override(-1, 0)
+
+
+def test_conv_concat_rowvec_residual_silu(ctx):
+    B, c1, c2, cout, H, W = 3, 64, 32, 96, 6, 5
+    xa, xb = rnd(B, c1, H, W), rnd(B, c2, H, W, seed=1)
+    w = rnd(cout, c1 + c2, 3, 3, scale=1 / math.sqrt(9 * (c1 + c2)))
+    b = rnd(cout, scale=0.1)
+    S = 4
+    rv = rnd(S, B, cout, seed=2)
+    step = torch.tensor([2], dtype=torch.int32, device=DEV)
+    res = rnd(B, cout, H, W, seed=3)
+    ref = conv_ref(torch.cat([xa, xb], 1), w, b) + rv[2][:, :, None, None]
+    ref = F.silu(ref) + res.half().float()
+    y = torch.zeros(B, H, W, cout, device=DEV, dtype=torch.float16)
+    d = make_desc(ctx, nhwc16(xa), w, b, y, x2=nhwc16(xb), flags=L.F_SILU, residual=nhwc16(res), rowvec=rv,
+                  rv_bs=cout, rv_ss=B * cout, step=step)
+    ctx.conv(d)
+    torch.cuda.synchronize()
+    check(y.permute(0, 3, 1, 2), ref)
+
+
+def test_conv_asym_pad_and_nchw_out(ctx):
+    B, cin, cout, H, W = 2, 32, 4, 8, 6
+    x = rnd(B, cin, H, W)
+    w = rnd(cout, cin, 3, 3, scale=0.1)
+    b = rnd(cout, scale=0.1)
+    ref = conv_ref(x, w, b, asym=True)
+    y = torch.zeros(B, ref.shape[2], ref.shape[3], 16, device=DEV, dtype=torch.float16)
+    ctx.conv(make_desc(ctx, nhwc16(x), w, b, y, stride=2, flags=L.F_PAD_ASYM))
+    torch.cuda.synchronize()
+    check(y[..., :cout].permute(0, 3, 1, 2), ref)
+    assert (y[..., cout:] == 0).all()
+    # fp32 NCHW output straight from the epilogue (UNet 'out' conv, VAE conv_out)
+    ref2 = conv_ref(x, w, b)
+    y2 = torch.zeros(B, cout, H, W, device=DEV)
+    d = make_desc(ctx, nhwc16(x), w, b, y2, flags=L.F_OUT_NCHW_F32)
+    d.ldy = 0
+    ctx.conv(d)
+    torch.cuda.synchronize()
+    check(y2, ref2, tol=2e-3)
+
+
+@pytest.mark.parametrize("M,K,N", [(96, 896, 224), (6144, 224, 224), (17, 768, 256), (50, 224, 896), (4608, 448, 448)])
+def test_gemm_bias_residual(ctx, M, K, N):
+    a = rnd(M, K).half()
+    w = rnd(N, K, scale=1 / math.sqrt(K))
+    b = rnd(N, scale=0.1)
+    res = rnd(M, N, seed=5).half()
+    ref = a.float() @ w.half().float().t() + b + res.float()
+    wp, n_pad = ctx.pack_weight(w)
+    bp = torch.zeros(n_pad, device=DEV); bp[:N] = b
+    y = torch.zeros(M, N, device=DEV, dtype=torch.float16)
+    ctx.gemm(a, K, M, K, wp, N, n_pad, bp, res, N, y, N, 0)
+    torch.cuda.synchronize()
+    check(y, ref)
+    # fp32 output
+    y32 = torch.zeros(M, N, device=DEV)
+    ctx.gemm(a, K, M, K, wp, N, n_pad, bp, None, 0, y32, N, L.F_OUT_F32)
+    torch.cuda.synchronize()
+    check(y32, ref - res.float(), tol=3e-3)
+
+
+def geglu_row_map(n_half):
+    """packed rows: per 64-row block [32 value rows | 32 gate rows] (include/upk.h UPK_F_GEGLU)."""
+    idx = torch.arange(2 * n_half)
+    blk, j = idx // 64, idx % 64
+    return torch.where(j < 32, blk * 32 + j, n_half + blk * 32 + (j - 32)).int()
+
+
+@pytest.mark.parametrize("M,d", [(768, 224), (96, 896)])
+def test_gemm_geglu(ctx, M, d):
+    inner = 4 * d
+    a = rnd(M, d).half()
+    w = rnd(2 * inner, d, scale=1 / math.sqrt(d))
+    b = rnd(2 * inner, scale=0.1)
+    h = a.float() @ w.half().float().t() + b
+    ref = h[:, :inner] * F.gelu(h[:, inner:])
+    rm = geglu_row_map(inner).to(DEV)
+    wp, n_pad = ctx.pack_weight(w, row_map=rm)
+    bp = b[rm.long()].contiguous()
+    y = torch.zeros(M, inner, device=DEV, dtype=torch.float16)
+    for sk in (0, 2):
+        ctx.conv_override(-1, sk)
+        y.zero_()
+        ctx.gemm(a, d, M, d, wp, inner, n_pad, bp, None, 0, y, inner, L.F_GEGLU)
+        torch.cuda.synchronize()
+        check(y, ref)
+    ctx.conv_override(-1, 0)
+
+
+def test_qkv_gemm_with_transposed_v(ctx):
+    """Fused q|k|v projection: q,k token-major, v written as V^T [B, heads, dpad, vt_ld];
+    head dim 28 padded to 32 by the packing row map."""
+    B, n, dm, heads, dh, dp = 2, 48, 224, 8, 28, 32
+    x = rnd(B * n, dm).half()
+    wq, wk, wv = (rnd(heads * dh, dm, scale=1 / math.sqrt(dm), seed=s) for s in (1, 2, 3))
+    w = torch.cat([wq, wk, wv], 0).contiguous()
+    hd = heads * dp
+    j = torch.arange(3 * hd)
+    part, r = j // hd, j % hd
+    h_, d_ = r // dp, r % dp
+    rm = torch.where(d_ < dh, part * heads * dh + h_ * dh + d_, torch.full_like(j, -1)).int().to(DEV)
+    wp, n_pad = ctx.pack_weight(w, row_map=rm)
+    assert n_pad == 3 * hd
+    vt_ld = 64
+    qk = torch.zeros(B * n, 2 * hd, device=DEV, dtype=torch.float16)
+    vt = torch.zeros(B, heads, dp, vt_ld, device=DEV, dtype=torch.float16)
+    d = L.ConvDesc()
+    d.x1 = x.data_ptr(); d.c1 = dm; d.ld1 = dm; d.batch = 1; d.in_h = B * n; d.in_w = 1; d.ksize = 1; d.stride = 1
+    d.w_packed = wp.data_ptr(); d.n_pad = n_pad; d.n_out = 2 * hd
+    d.y = qk.data_ptr(); d.ldy = 2 * hd
+    d.vt = vt.data_ptr(); d.vt_from = 2 * hd; d.vt_heads = heads; d.vt_dhead = dp; d.vt_ld = vt_ld; d.vt_tokens = n
+    ctx.conv(d)
+    torch.cuda.synchronize()
+    xf = x.float()
+    for name, wmat, got in (("q", wq, qk[:, :hd]), ("k", wk, qk[:, hd:])):
+        ref = (xf @ wmat.half().float().t()).view(B * n, heads, dh)
+        g = got.view(B * n, heads, dp)
+        check(g[..., :dh], ref)
+        assert (g[..., dh:] == 0).all()
+    vref = (xf @ wv.half().float().t()).view(B, n, heads, dh).permute(0, 2, 3, 1)  # B,h,d,n
+    check(vt[:, :, :dh, :n], vref)
+    assert (vt[:, :, dh:, :] == 0).all() and (vt[..., n:] == 0).all()
+
+
+@pytest.mark.parametrize("d,nq,nkv,heads", [(32, 768, 768, 8), (64, 192, 87, 8), (128, 48, 48, 8), (128, 12, 12, 8),
+                                            (32, 100, 87, 2), (512, 200, 200, 1)])
+def test_attention(ctx, d, nq, nkv, heads):
+    B = 2
+    q = rnd(B, nq, heads * d).half()
+    k = rnd(B, nkv, heads * d, seed=1).half()
+    v = rnd(B, nkv, heads * d, seed=2).half()
+    scale = d ** -0.5
+    vt_ld = (nkv + 31) // 32 * 32
+    vt = torch.zeros(B, heads, d, vt_ld, device=DEV, dtype=torch.float16)
+    vt[..., :nkv] = v.view(B, nkv, heads, d).permute(0, 2, 3, 1)
+    out = torch.zeros(B, nq, heads * d, device=DEV, dtype=torch.float16)
+    ctx.attention(q, heads * d, nq * heads * d, k, heads * d, nkv * heads * d, vt, vt_ld, out, heads * d,
+                  nq * heads * d, B, heads, nq, nkv, d, scale)
+    torch.cuda.synchronize()
+    qf = q.float().view(B, nq, heads, d).transpose(1, 2)
+    kf = k.float().view(B, nkv, heads, d).transpose(1, 2)
+    vf = v.float().view(B, nkv, heads, d).transpose(1, 2)
+    ref = torch.softmax(qf @ kf.transpose(-1, -2) * scale, -1) @ vf
+    check(out.view(B, nq, heads, d).transpose(1, 2), ref, tol=1e-2)
+
+
+def test_attention_online_softmax_rescale(ctx):
+    """A late key with a huge score forces the running-max rescale branch."""
+    B, heads, d, nq, nkv = 1, 1, 64, 16, 96
+    q = rnd(B, nq, d).half()
+    k = rnd(B, nkv, d, seed=1).half()
+    k[0, 70] = q[0, 3] * 4
+    v = rnd(B, nkv, d, seed=2).half()
+    vt = v.permute(0, 2, 1).contiguous().view(B, 1, d, nkv)
+    out = torch.zeros(B, nq, d, device=DEV, dtype=torch.float16)
+    ctx.attention(q, d, nq * d, k, d, nkv * d, vt, nkv, out, d, nq * d, B, heads, nq, nkv, d, 1.0)
+    torch.cuda.synchronize()
+    ref = torch.softmax(q.float() @ k.float().transpose(-1, -2), -1) @ v.float()
+    check(out, ref, tol=1e-2)
+
+
+@pytest.mark.parametrize("c1,c2,hw,silu,eps", [(224, 0, 768, True, 1e-5), (896, 448, 192, True, 1e-5),
+                                               (448, 0, 12, False, 1e-6), (128, 0, 4096, True, 1e-6),
+                                               (896, 896, 48, True, 1e-5), (448, 224, 768, True, 1e-5)])
+def test_groupnorm(ctx, c1, c2, hw, silu, eps):
+    B, C = 3, c1 + c2
+    xa = (rnd(B, hw, c1) * 2 + 0.5).half()
+    xb = (rnd(B, hw, c2, seed=1) - 0.3).half() if c2 else None
+    gamma = 1 + 0.1 * rnd(C, seed=2)
+    beta = 0.1 * rnd(C, seed=3)
+    x = torch.cat([xa, xb], -1) if c2 else xa
+    ref = F.group_norm(x.float().permute(0, 2, 1), 32, gamma, beta, eps).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    y = torch.zeros(B, hw, C, device=DEV, dtype=torch.float16)
+    ws = torch.zeros(ctx.groupnorm_ws_bytes(B, hw) // 4, device=DEV)
+    ctx.groupnorm(xa, c1, c1, xb, c2, c2 if c2 else 0, B, hw, 32, gamma, beta, eps, silu, y, C, ws)
+    torch.cuda.synchronize()
+    check(y, ref, tol=4e-3)
+    y2 = torch.zeros_like(y)
+    ctx.groupnorm(xa, c1, c1, xb, c2, c2 if c2 else 0, B, hw, 32, gamma, beta, eps, silu, y2, C, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2), "GroupNorm must be bitwise reproducible"
+
+
+@pytest.mark.parametrize("rows,d", [(6144, 224), (1536, 448), (97, 896), (5, 1024), (33, 2048)])
+def test_layernorm(ctx, rows, d):
+    x = (rnd(rows, d) * 3 + 1).half()
+    gamma = 1 + 0.1 * rnd(d, seed=2)
+    beta = 0.1 * rnd(d, seed=3)
+    ref = F.layer_norm(x.float(), (d,), gamma, beta, 1e-5)
+    y = torch.zeros(rows, d, device=DEV, dtype=torch.float16)
+    ctx.layernorm(x, d, rows, d, gamma, beta, 1e-5, y, d)
+    torch.cuda.synchronize()
+    check(y, ref, tol=2e-3)
+
+
+def test_timestep_embed(ctx):
+    t = torch.tensor([0., 1., 21., 500., 981., 999.], device=DEV)
+    dim = 224
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half).to(DEV)
+    args = t[:, None] * freqs[None]
+    ref = torch.cat([torch.cos(args), torch.sin(args)], -1)
+    out = torch.zeros(6, 224, device=DEV, dtype=torch.float16)
+    ctx.timestep_embed(t, 6, dim, 10000.0, out, 224)
+    torch.cuda.synchronize()
+    assert (out.float() - ref).abs().max() < 2e-3
+
+
+def test_layout_and_ddim_step(ctx):
+    B, Cc, H, W = 2, 4, 6, 5
+    hw = H * W
+    x = rnd(B, Cc, H, W)
+    mask = rnd(B, 1, H, W, seed=1)
+    xin = torch.full((B, hw, 32), 7.0, device=DEV, dtype=torch.float16)
+    ctx.nchw_to_nhwc(x, B, Cc, hw, xin, 32, 0, 0, 1.0)
+    ctx.nchw_to_nhwc(mask, B, 1, hw, xin, 32, Cc, 32, 1.0)
+    torch.cuda.synchronize()
+    ref = torch.cat([x, mask], 1).permute(0, 2, 3, 1).reshape(B, hw, 5).half()
+    assert torch.equal(xin[..., :5], ref) and (xin[..., 5:] == 0).all()
+    back = torch.zeros(B, 5, H, W, device=DEV)
+    ctx.nhwc_to_nchw(xin, 32, B, 5, hw, back)
+    torch.cuda.synchronize()
+    assert torch.equal(back, torch.cat([x, mask], 1).half().float())
+    # ddim update (ddim.py:189-203)
+    S = 3
+    coefs = torch.rand(S, 4, device=DEV) + 0.1
+    noise = rnd(S, B, Cc, H, W, seed=4)
+    e = rnd(B, Cc, H, W, seed=5)
+    step = torch.tensor([1], dtype=torch.int32, device=DEV)
+    x0 = x.clone()
+    pred = torch.zeros_like(x)
+    ctx.ddim_step(x, e, coefs, noise, step, pred, xin, 32, B, Cc, hw)
+    ctx.advance_step(step)
+    torch.cuda.synchronize()
+    c = coefs[1]
+    p_ref = (x0 - c[0] * e) * c[1]
+    x_ref = c[2] * p_ref + c[3] * e + noise[1]
+    assert torch.allclose(pred, p_ref, atol=1e-5) and torch.allclose(x, x_ref, atol=1e-5)
+    assert torch.equal(xin[..., :4], x.permute(0, 2, 3, 1).reshape(B, hw, 4).half())
+    assert step.item() == 2
+
+
+def test_graph_capture_replay(ctx):
+    """A captured sequence replays with the device-side step counter advancing."""
+    M, K, N = 64, 64, 64
+    a = rnd(M, K).half()
+    w = rnd(N, K, scale=0.1)
+    wp, n_pad = ctx.pack_weight(w)
+    y = torch.zeros(M, N, device=DEV, dtype=torch.float16)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        ctx.graph_begin()
+        ctx.gemm(a, K, M, K, wp, N, n_pad, None, None, 0, y, N, 0)
+        ctx.advance_step(step)
+        g = ctx.graph_end()
+        for _ in range(5):
+            ctx.graph_launch(g)
+    s.synchronize()
+    assert step.item() == 5
+    check(y, a.float() @ w.half().float().t())
+    ctx.graph_destroy(g)
+
+
+def test_errors_are_reported(ctx):
+    d = L.ConvDesc()
+    with pytest.raises(L.UpkError):
+        ctx.conv(d)
+    a = rnd(16, 40).half()
+    with pytest.raises(L.UpkError) as ei:
+        ctx.gemm(a, 40, 16, 40, a, 16, 16, None, None, 0, a, 16, 0)  # K not a multiple of 32
+    assert ei.value.code == -2

@@ -1,0 +1,94 @@
+// Internal header of libupk.so (gfx950 only). Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/upk.h"
+
+typedef _Float16 f16;
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+enum { UPK_CLS_IGEMM = 0, UPK_CLS_ATTN = 1, UPK_CLS_GN = 2, UPK_CLS_LN = 3, UPK_CLS_OTHER = 4 };
+
+struct upk_prof_rec {
+  hipEvent_t e0, e1;
+  int cls;
+};
+
+struct upk_ctx {
+  int device;
+  int num_cus;
+  char err[512];
+  void* ws;
+  size_t ws_bytes;
+  int cfg_override;
+  int splitk_override;
+  // profiling
+  int prof_on;
+  std::vector<upk_prof_rec> recs;       // recorded, not yet collected
+  std::vector<upk_prof_rec> free_recs;  // reusable event pairs
+  double prof_ms[UPK_NUM_CLASSES];
+  long long prof_n[UPK_NUM_CLASSES];
+};
+
+static inline int upk_fail(upk_ctx* ctx, int code, const char* fmt, ...) __attribute__((format(printf, 3, 4)));
+static inline int upk_fail(upk_ctx* ctx, int code, const char* fmt, ...) {
+  if (ctx) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define UPK_HIP(ctx, call)                                                              \
+  do {                                                                                  \
+    hipError_t e__ = (call);                                                            \
+    if (e__ != hipSuccess)                                                              \
+      return upk_fail(ctx, UPK_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                      __FILE__, __LINE__);                                              \
+  } while (0)
+
+// Brackets a kernel launch with HIP events on its own stream when profiling.
+struct upk_prof_scope {
+  upk_ctx* ctx;
+  hipStream_t s;
+  upk_prof_rec rec;
+  bool on;
+  upk_prof_scope(upk_ctx* c, int cls, hipStream_t st) : ctx(c), s(st), on(false) {
+    if (!c || !c->prof_on) return;
+    if (!c->free_recs.empty()) {
+      rec = c->free_recs.back();
+      c->free_recs.pop_back();
+    } else {
+      if (hipEventCreate(&rec.e0) != hipSuccess) return;
+      if (hipEventCreate(&rec.e1) != hipSuccess) return;
+    }
+    rec.cls = cls;
+    on = (hipEventRecord(rec.e0, s) == hipSuccess);
+  }
+  ~upk_prof_scope() {
+    if (!on) return;
+    (void)hipEventRecord(rec.e1, s);
+    ctx->recs.push_back(rec);
+  }
+};
+
+static inline int upk_check_launch(upk_ctx* ctx, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return upk_fail(ctx, UPK_EHIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+  return UPK_OK;
+}
+
+__device__ __forceinline__ float upk_silu(float v) { return v / (1.0f + __expf(-v)); }
+// exact (erf) GELU, attention.py:44 (F.gelu default)
+__device__ __forceinline__ float upk_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }

@@ -1,0 +1,556 @@
+// Implicit-GEMM convolution / Linear for gfx950 (CDNA4), fp16 in, fp32 accumulate.
+//
+//   y[m, n] = epilogue( sum_k A[m, k] * W[n, k] )
+//   m = (b, oy, ox)  over the output pixels (token-major NHWC)
+//   k = (tap, ci)    tap = ky*ks+kx, ci over the (possibly two-source) input channels
+//
+// Mapping to the hardware:
+//   * v_mfma_f32_16x16x32_f16 (8 fp16 per lane per operand, 4 fp32 acc per lane),
+//     operands SWAPPED (weights = A operand, activations = B operand) so that a lane
+//     ends up with 4 consecutive output channels of one pixel -> 8-byte NHWC stores.
+//   * K is walked in 32-wide chunks that never straddle a tap (channels are padded to
+//     32), so the im2col address of a chunk is one scalar tap offset + a per-row pixel.
+//   * global -> registers -> LDS double buffering, one barrier per K chunk; LDS tiles are
+//     [rows][32 fp16] with a 16-byte-chunk XOR swizzle that makes ds_read_b128 of the
+//     MFMA fragments conflict free (see lds_swz()).
+//   * weights are pre-packed [K/32][n_pad][32] so a B tile is ONE contiguous run.
+//   * split-K over blockIdx.z with fp32 partial slabs in caller workspace and a
+//     deterministic reduce+epilogue kernel (deep UNet levels have M = 96..384 rows only).
+//
+// Replaces F.conv2d / F.linear at the call sites listed in include/upk.h.
+#include "common.h"
+
+namespace {
+
+struct IgemmArgs {
+  const f16* x1;
+  const f16* x2;
+  int c1, c2, ld1, ld2;
+  const f16* w;
+  int npad;
+  const float* bias;
+  const f16* res;
+  int ldr;
+  const float* rowvec;
+  int rv_bs, rv_ss;
+  const int* step;
+  void* y;
+  int ldy;
+  f16* vt;
+  int vt_from, vt_heads, vt_dhead, vt_ld, vt_tokens;
+  float* partial;  // split-K slabs [splitk][M][npad] fp32, or nullptr
+  int M, n_out;
+  int B, HS, WS;   // stored input dims
+  int HL, WL;      // logical input dims (after optional 2x upsample)
+  int Ho, Wo;
+  int ks, stride, pad_lo, ups;
+  int cpt;         // 32-wide chunks per tap = (c1+c2)/32
+  int nchunks;     // ks*ks*cpt
+  int chunks_per_split;
+  int tiles_m, tiles_n;
+  int flags;
+};
+
+// 16-byte chunk swizzle for a [rows][4 chunks] fp16 tile (64 B rows).
+// ds_read_b128 is serviced in four 16-lane groups {0-3,12-15,20-27},{4-11,16-19,28-31},...
+// With fragment lane l reading row (l&15), chunk (l>>4), XOR-ing the chunk with
+// (-(row>>2))&3 puts the 16 lanes of every group on 16 distinct 16-B slots of the
+// 256-B bank row.
+__device__ __forceinline__ int lds_swz(int row, int chunk) { return chunk ^ ((-(row >> 2)) & 3); }
+
+struct Epi {
+  // Applies bias / rowvec / activation / residual and stores 4 consecutive packed
+  // columns [n, n+4) of row m. v = value accumulators, g = gate accumulators (GEGLU).
+  static __device__ __forceinline__ void store(const IgemmArgs& a, int m, int n, f32x4 v, f32x4 g) {
+    if (m >= a.M) return;
+    const int flags = a.flags;
+    int oc = n;  // output column
+    if (flags & UPK_F_GEGLU) {
+      // packed rows: [32 value | 32 gate] per 64-row block
+      if (a.bias) {
+        f32x4 bv = *(const f32x4*)(a.bias + n);
+        f32x4 bg = *(const f32x4*)(a.bias + n + 32);
+        v += bv;
+        g += bg;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = v[r] * upk_gelu(g[r]);
+      oc = (n >> 6) * 32 + (n & 31);
+    } else {
+      if (a.bias) v += *(const f32x4*)(a.bias + n);
+    }
+    if (oc >= a.n_out && !(a.vt && n >= a.vt_from)) return;
+    int b = 0, p = m;
+    if (a.rowvec || (flags & UPK_F_OUT_NCHW_F32)) {
+      const int hw = a.Ho * a.Wo;
+      b = m / hw;
+      p = m - b * hw;
+    }
+    if (a.rowvec) {
+      const int st = a.step ? *a.step : 0;
+      const float* rv = a.rowvec + (long)st * a.rv_ss + (long)b * a.rv_bs + n;
+      v += *(const f32x4*)rv;
+    }
+    if (flags & UPK_F_SILU) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = upk_silu(v[r]);
+    }
+    if (a.vt && n >= a.vt_from) {
+      const int cc = n - a.vt_from;
+      const int h = cc / a.vt_dhead;
+      const int d = cc - h * a.vt_dhead;
+      const int bb = m / a.vt_tokens;
+      const int tok = m - bb * a.vt_tokens;
+      f16* dst = a.vt + ((long)(bb * a.vt_heads + h) * a.vt_dhead + d) * a.vt_ld + tok;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(long)r * a.vt_ld] = (f16)v[r];
+      return;
+    }
+    if (a.res) {
+      f16x4 rr = *(const f16x4*)(a.res + (long)m * a.ldr + oc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+    }
+    if (flags & UPK_F_OUT_NCHW_F32) {
+      float* yo = (float*)a.y;
+      const long hw = (long)a.Ho * a.Wo;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (oc + r < a.n_out) yo[((long)b * a.n_out + oc + r) * hw + p] = v[r];
+    } else if (flags & UPK_F_OUT_F32) {
+      float* yo = (float*)a.y + (long)m * a.ldy + oc;
+      if (oc + 3 < a.n_out) {
+        *(f32x4*)yo = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (oc + r < a.n_out) yo[r] = v[r];
+      }
+    } else {
+      f16* yo = (f16*)a.y + (long)m * a.ldy + oc;
+      if (oc + 3 < a.n_out) {
+        f16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (f16)v[r];
+        *(f16x4*)yo = o;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (oc + r < a.n_out) yo[r] = (f16)v[r];
+      }
+    }
+  }
+};
+
+template <int MI, int NI, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
+  constexpr int BM = MI * 16 * WM;
+  constexpr int BN = NI * 16 * WN;
+  constexpr int NT = WM * WN * 64;
+  constexpr int A_IT = (BM * 4 + NT - 1) / NT;
+  constexpr int B_IT = (BN * 4 + NT - 1) / NT;
+  constexpr int A_TILE = BM * 32;  // halfs
+  constexpr int B_TILE = BN * 32;
+
+  __shared__ __attribute__((aligned(16))) f16 smem[2 * (A_TILE + B_TILE)];
+  f16* sA = smem;               // [2][A_TILE]
+  f16* sB = smem + 2 * A_TILE;  // [2][B_TILE]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN;
+  const int wn = wave - wm * WN;
+  const int lg = lane >> 4;  // k-chunk group 0..3
+  const int lc = lane & 15;
+
+  // tile coordinates: consecutive blocks walk M first (they share the weight tile in L2)
+  const int tile = blockIdx.x;
+  const int tn = tile / a.tiles_m;
+  const int tm = tile - tn * a.tiles_m;
+  const int m0 = tm * BM;
+  const int n0 = tn * BN;
+  const int kc0 = blockIdx.z * a.chunks_per_split;
+  const int kc1 = min(a.nchunks, kc0 + a.chunks_per_split);
+
+  // ---- per-thread A rows (im2col pixel decode, done once) ----
+  int a_oy[A_IT], a_ox[A_IT], a_b[A_IT];
+  bool a_ok[A_IT];
+  const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int q = tid + i * NT;
+    const int row = q >> 2;
+    const int m = m0 + row;
+    a_ok[i] = (row < BM) && (m < a.M);
+    const int mm = a_ok[i] ? m : 0;
+    const int b = mm / HoWo;
+    const int p = mm - b * HoWo;
+    const int oy = p / a.Wo;
+    a_b[i] = b;
+    a_oy[i] = oy * a.stride - a.pad_lo;
+    a_ox[i] = (p - oy * a.Wo) * a.stride - a.pad_lo;
+  }
+
+  f16x8 ra[A_IT], rb[B_IT];
+  const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  auto load_tiles = [&](int kc) {
+    const int tap = kc / a.cpt;
+    const int c0 = (kc - tap * a.cpt) * 32;
+    const int ky = tap / a.ks;
+    const int kx = tap - ky * a.ks;
+    const bool second = (c0 >= a.c1);
+    const f16* src = second ? a.x2 : a.x1;
+    const int ld = second ? a.ld2 : a.ld1;
+    const int cb = second ? c0 - a.c1 : c0;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int q = tid + i * NT;
+      const int ch = q & 3;
+      int iy = a_oy[i] + ky;
+      int ix = a_ox[i] + kx;
+      const bool ok = a_ok[i] && iy >= 0 && iy < a.HL && ix >= 0 && ix < a.WL;
+      if (a.ups) {
+        iy >>= 1;
+        ix >>= 1;
+      }
+      const long pix = ((long)a_b[i] * a.HS + iy) * a.WS + ix;
+      ra[i] = ok ? *(const f16x8*)(src + pix * ld + cb + ch * 8) : zero8;
+    }
+    const f16* wb = a.w + ((long)kc * a.npad + n0) * 32;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int q = tid + i * NT;
+      const int row = q >> 2;
+      const bool ok = (row < BN) && (n0 + row < a.npad);
+      rb[i] = ok ? *(const f16x8*)(wb + (long)q * 8) : zero8;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    f16* dA = sA + buf * A_TILE;
+    f16* dB = sB + buf * B_TILE;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int q = tid + i * NT;
+      const int row = q >> 2;
+      if (row < BM) *(f16x8*)(dA + row * 32 + lds_swz(row, q & 3) * 8) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const int q = tid + i * NT;
+      const int row = q >> 2;
+      if (row < BN) *(f16x8*)(dB + row * 32 + lds_swz(row, q & 3) * 8) = rb[i];
+    }
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment offset of this lane inside a 16-row sub-tile (swizzle depends on row&15 only)
+  const int frag_off = lc * 32 + lds_swz(lc, lg) * 8;
+  const int a_base = wm * (MI * 16) * 32 + frag_off;
+  const int b_base = wn * (NI * 16) * 32 + frag_off;
+
+  if (kc0 < kc1) {
+    load_tiles(kc0);
+    store_tiles(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int kc = kc0; kc < kc1; ++kc) {
+    const bool more = (kc + 1 < kc1);
+    if (more) load_tiles(kc + 1);
+    const f16* tA = sA + cur * A_TILE + a_base;
+    const f16* tB = sB + cur * B_TILE + b_base;
+    f16x8 fa[MI], fb[NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) fa[i] = *(const f16x8*)(tA + i * 512);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) fb[j] = *(const f16x8*)(tB + j * 512);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    if (more) store_tiles(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: lane (lg, lc) holds rows m = .. + lc, cols n = .. + 4*lg + r ----
+  const int mw = m0 + wm * (MI * 16);
+  const int nw = n0 + wn * (NI * 16);
+  if (a.partial) {
+    float* slab = a.partial + (long)blockIdx.z * a.M * a.npad;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = mw + i * 16 + lc;
+      if (m >= a.M) continue;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = nw + j * 16 + lg * 4;
+        if (n < a.npad) *(f32x4*)(slab + (long)m * a.npad + n) = acc[i][j];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = mw + i * 16 + lc;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = nw + j * 16 + lg * 4;
+      if (n >= a.npad) continue;
+      if (a.flags & UPK_F_GEGLU) {
+        if constexpr (NI % 4 == 0) {
+          if ((j & 2) == 0) Epi::store(a, m, n, acc[i][j], acc[i][j + 2 < NI ? j + 2 : j]);
+        }
+      } else {
+        Epi::store(a, m, n, acc[i][j], acc[i][j]);
+      }
+    }
+  }
+}
+
+// Split-K second pass: sums the slabs in fixed order (deterministic) and runs the epilogue.
+__global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmArgs a, int splitk) {
+  const int nq = a.npad >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)a.M * nq;
+  if (idx >= total) return;
+  const int m = (int)(idx / nq);
+  const int n = (int)(idx - (long)m * nq) * 4;
+  const long slab = (long)a.M * a.npad;
+  const float* p = a.partial + (long)m * a.npad + n;
+  f32x4 v = {0, 0, 0, 0}, g = {0, 0, 0, 0};
+  if (a.flags & UPK_F_GEGLU) {
+    if (n & 32) return;  // gate columns are consumed by their value partner
+    for (int z = 0; z < splitk; ++z) {
+      v += *(const f32x4*)(p + z * slab);
+      g += *(const f32x4*)(p + z * slab + 32);
+    }
+  } else {
+    for (int z = 0; z < splitk; ++z) v += *(const f32x4*)(p + z * slab);
+  }
+  IgemmArgs b = a;
+  b.partial = nullptr;
+  Epi::store(b, m, n, v, g);
+}
+
+struct CfgInfo {
+  int mi, ni, wm, wn;
+  const char* name;
+  void (*fn)(const IgemmArgs);
+};
+
+#define CFG(MI, NI, WM, WN) {MI, NI, WM, WN, #MI "x" #NI "x" #WM "x" #WN, igemm_kernel<MI, NI, WM, WN>}
+// (MI, NI, WM, WN): block tile = (MI*16*WM) x (NI*16*WN), WM*WN waves.
+const CfgInfo kCfgs[] = {
+    CFG(4, 4, 2, 2),  // 0: 128x128
+    CFG(2, 4, 2, 2),  // 1:  64x128
+    CFG(4, 2, 2, 2),  // 2: 128x64
+    CFG(2, 2, 2, 2),  // 3:  64x64
+    CFG(2, 4, 4, 1),  // 4: 128x64   (wave 32x64, GEGLU capable)
+    CFG(1, 4, 4, 1),  // 5:  64x64   (wave 16x64, GEGLU capable)
+    CFG(4, 7, 2, 2),  // 6: 128x224  (7-family: 224 = 7*32)
+    CFG(2, 7, 2, 2),  // 7:  64x224
+    CFG(1, 7, 2, 2),  // 8:  32x224
+    CFG(2, 7, 4, 1),  // 9: 128x112
+    CFG(1, 7, 4, 1),  // 10: 64x112
+    CFG(1, 7, 2, 1),  // 11: 32x112  (2 waves)
+    CFG(2, 1, 4, 1),  // 12: 128x16  (N <= 16: UNet/VAE output convs)
+    CFG(1, 2, 4, 1),  // 13: 64x32
+    CFG(1, 4, 1, 4),  // 14: 16x256  (tiny M: emb / context projections)
+    CFG(1, 2, 2, 2),  // 15: 32x64
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Rough cycle model used to pick (config, split-K). Tuned on MI355X; override with
+// upk_conv_override for experiments.
+double estimate(const CfgInfo& c, int M, int npad, int nchunks, int splitk, int cus, bool geglu) {
+  const int BM = c.mi * 16 * c.wm, BN = c.ni * 16 * c.wn;
+  const int waves = c.wm * c.wn;
+  if (geglu && ((c.ni * 16) % 64 != 0)) return 1e30;
+  const int tiles = cdiv(M, BM) * cdiv(npad, BN);
+  const long wgs = (long)tiles * splitk;
+  const int chunks = cdiv(nchunks, splitk);
+  // per K-chunk cycles of one workgroup
+  const double mfma = c.mi * c.ni * 16.0 * (waves > 4 ? waves / 4.0 : 1.0);
+  const double lds = (c.mi + c.ni) * 4.0 * waves + (BM + BN) * 4 * 13.0 / 64.0 / 4.0;
+  const double gl = (BM + BN) * 64.0 / 40.0;  // bytes / (B/clk/CU sustained from L2)
+  double per_chunk = fmax(fmax(mfma, lds), gl) + 90.0;  // + barrier / issue overhead
+  // workgroups resident per CU (LDS + registers), they overlap each other's stalls
+  const int lds_bytes = 2 * (BM + BN) * 64;
+  int occ = 160 * 1024 / lds_bytes;
+  const int regs = c.mi * c.ni * 4 + (c.mi + c.ni) * 8 + 40;
+  int occ_r = (512 / regs) * 4 / waves;
+  if (occ_r < 1) occ_r = 1;
+  if (occ > occ_r) occ = occ_r;
+  if (occ > 4) occ = 4;
+  const double slots = (double)cus * occ;
+  const double rounds = ceil(wgs / slots);
+  // co-resident workgroups share the CU: each runs ~occ x slower but hides latency
+  const double eff = (occ >= 2) ? 0.75 : 1.0;
+  double t = rounds * (chunks * per_chunk * occ * eff + 1500.0);
+  if (splitk > 1) t += 4000.0 + (double)M * npad * splitk * 4.0 / (cus * 40.0);
+  return t;
+}
+
+}  // namespace
+
+extern "C" int upk_conv_num_configs(void) { return kNumCfgs; }
+extern "C" const char* upk_conv_config_name(int cfg) {
+  return (cfg >= 0 && cfg < kNumCfgs) ? kCfgs[cfg].name : "?";
+}
+extern "C" int upk_conv_override(upk_ctx* ctx, int cfg, int splitk) {
+  if (!ctx) return UPK_EINVAL;
+  ctx->cfg_override = cfg;
+  ctx->splitk_override = splitk;
+  return UPK_OK;
+}
+
+extern "C" int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_) {
+  if (!ctx || !d) return UPK_EINVAL;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!d->x1 || !d->w_packed || !d->y) return upk_fail(ctx, UPK_EINVAL, "conv: null x1/w/y");
+  if (d->c1 <= 0 || (d->c1 & 31) || (d->c2 & 31) || d->c2 < 0)
+    return upk_fail(ctx, UPK_ESHAPE, "conv: channels must be multiples of 32 (c1=%d c2=%d)", d->c1, d->c2);
+  if (d->c2 > 0 && !d->x2) return upk_fail(ctx, UPK_EINVAL, "conv: c2>0 but x2 null");
+  if (d->ksize != 1 && d->ksize != 3) return upk_fail(ctx, UPK_ESHAPE, "conv: ksize %d", d->ksize);
+  if (d->stride != 1 && d->stride != 2) return upk_fail(ctx, UPK_ESHAPE, "conv: stride %d", d->stride);
+  if ((d->ld1 & 7) || (d->c2 && (d->ld2 & 7)) || (d->n_pad & 15) || d->n_pad <= 0)
+    return upk_fail(ctx, UPK_EINVAL, "conv: leading dims must be multiples of 8, n_pad of 16");
+  const int flags = d->flags;
+  const bool geglu = flags & UPK_F_GEGLU;
+  if (geglu && (d->n_pad & 63)) return upk_fail(ctx, UPK_ESHAPE, "conv: GEGLU needs n_pad %% 64 == 0");
+  if (!(flags & UPK_F_OUT_NCHW_F32) && (d->ldy & 3)) return upk_fail(ctx, UPK_EINVAL, "conv: ldy %% 4");
+  if (d->residual && (d->ld_res & 3)) return upk_fail(ctx, UPK_EINVAL, "conv: ld_res %% 4");
+
+  IgemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x1 = (const f16*)d->x1;
+  a.x2 = (const f16*)d->x2;
+  a.c1 = d->c1;
+  a.c2 = d->c2;
+  a.ld1 = d->ld1;
+  a.ld2 = d->ld2;
+  a.w = (const f16*)d->w_packed;
+  a.npad = d->n_pad;
+  a.bias = d->bias;
+  a.res = (const f16*)d->residual;
+  a.ldr = d->ld_res;
+  a.rowvec = d->rowvec;
+  a.rv_bs = d->rv_batch_stride;
+  a.rv_ss = d->rv_step_stride;
+  a.step = d->step;
+  a.y = d->y;
+  a.ldy = d->ldy;
+  a.vt = (f16*)d->vt;
+  a.vt_from = d->vt_from;
+  a.vt_heads = d->vt_heads;
+  a.vt_dhead = d->vt_dhead;
+  a.vt_ld = d->vt_ld;
+  a.vt_tokens = d->vt_tokens;
+  if (a.vt && (a.vt_dhead <= 0 || (a.vt_dhead & 3) || (a.vt_from & 3) || a.vt_tokens <= 0))
+    return upk_fail(ctx, UPK_EINVAL, "conv: bad vt_* parameters");
+  a.n_out = d->n_out;
+  a.B = d->batch;
+  a.HS = d->in_h;
+  a.WS = d->in_w;
+  a.ups = (flags & UPK_F_UPSAMPLE2X) ? 1 : 0;
+  a.HL = a.ups ? 2 * a.HS : a.HS;
+  a.WL = a.ups ? 2 * a.WS : a.WS;
+  a.ks = d->ksize;
+  a.stride = d->stride;
+  const int pad = (d->ksize == 3) ? 1 : 0;
+  if (flags & UPK_F_PAD_ASYM) {
+    if (d->stride != 2 || d->ksize != 3) return upk_fail(ctx, UPK_ESHAPE, "conv: PAD_ASYM needs 3x3 s2");
+    a.pad_lo = 0;
+    a.Ho = (a.HL + 1 - 3) / 2 + 1;
+    a.Wo = (a.WL + 1 - 3) / 2 + 1;
+  } else {
+    a.pad_lo = pad;
+    a.Ho = (a.HL + 2 * pad - d->ksize) / d->stride + 1;
+    a.Wo = (a.WL + 2 * pad - d->ksize) / d->stride + 1;
+  }
+  a.M = a.B * a.Ho * a.Wo;
+  if (a.M <= 0) return upk_fail(ctx, UPK_EINVAL, "conv: empty output");
+  a.cpt = (a.c1 + a.c2) / 32;
+  a.nchunks = a.ks * a.ks * a.cpt;
+  a.flags = flags;
+
+  // ---- choose config + split-K ----
+  int best = -1, best_sk = 1;
+  double best_t = 1e30;
+  const int sk_cands[] = {1, 2, 3, 4, 6, 8, 9, 12, 16, 18};
+  const size_t slab = (size_t)a.M * a.npad * sizeof(float);
+  for (int c = 0; c < kNumCfgs; ++c) {
+    if (ctx->cfg_override >= 0 && c != ctx->cfg_override) continue;
+    for (int sk : sk_cands) {
+      if (ctx->splitk_override > 0 && sk != ctx->splitk_override) continue;
+      if (sk > 1 && (slab * sk > ctx->ws_bytes || a.nchunks / sk < 4)) continue;
+      const double t = estimate(kCfgs[c], a.M, a.npad, a.nchunks, sk, ctx->num_cus, geglu);
+      if (t < best_t) {
+        best_t = t;
+        best = c;
+        best_sk = sk;
+      }
+    }
+  }
+  if (best < 0) {
+    if (ctx->splitk_override > 1 && slab * ctx->splitk_override > ctx->ws_bytes)
+      return upk_fail(ctx, UPK_EWORKSPACE, "conv: split-K %d needs %zu workspace bytes, have %zu",
+                      ctx->splitk_override, slab * ctx->splitk_override, ctx->ws_bytes);
+    return upk_fail(ctx, UPK_ESHAPE, "conv: no kernel configuration fits (geglu=%d)", (int)geglu);
+  }
+  const CfgInfo& c = kCfgs[best];
+  const int BM = c.mi * 16 * c.wm, BN = c.ni * 16 * c.wn;
+  a.tiles_m = cdiv(a.M, BM);
+  a.tiles_n = cdiv(a.npad, BN);
+  a.chunks_per_split = cdiv(a.nchunks, best_sk);
+  const int zdim = cdiv(a.nchunks, a.chunks_per_split);
+  a.partial = (zdim > 1) ? (float*)ctx->ws : nullptr;
+
+  upk_prof_scope prof(ctx, UPK_CLS_IGEMM, stream);
+  dim3 grid(a.tiles_m * a.tiles_n, 1, zdim);
+  hipLaunchKernelGGL(c.fn, grid, dim3(c.wm * c.wn * 64), 0, stream, a);
+  int rc = upk_check_launch(ctx, "igemm");
+  if (rc) return rc;
+  if (zdim > 1) {
+    const long total = (long)a.M * (a.npad / 4);
+    hipLaunchKernelGGL(igemm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, zdim);
+    rc = upk_check_launch(ctx, "igemm_reduce");
+  }
+  return rc;
+}
+
+extern "C" int upk_gemm_f16(upk_ctx* ctx, const void* A, int lda, int m, int k, const void* w_packed,
+                            int n_out, int n_pad, const float* bias, const void* residual, int ld_res,
+                            void* y, int ldy, int flags, upk_stream stream) {
+  upk_conv_desc d;
+  memset(&d, 0, sizeof(d));
+  d.x1 = A;
+  d.c1 = k;
+  d.ld1 = lda;
+  d.batch = 1;
+  d.in_h = m;
+  d.in_w = 1;
+  d.ksize = 1;
+  d.stride = 1;
+  d.w_packed = w_packed;
+  d.n_out = n_out;
+  d.n_pad = n_pad;
+  d.bias = bias;
+  d.residual = residual;
+  d.ld_res = ld_res;
+  d.y = y;
+  d.ldy = ldy;
+  d.flags = flags;
+  return upk_conv2d_nhwc_f16(ctx, &d, stream);
+}

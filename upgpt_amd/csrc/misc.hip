@@ -1,0 +1,316 @@
+// Context, weight packing, layout conversion, timestep embedding, DDIM update,
+// HIP-graph helpers and event profiling of libupk.so (gfx950).
+#include <stdarg.h>
+
+#include "common.h"
+
+// ------------------------------------------------------------------ context
+extern "C" int upk_version(void) { return UPK_VERSION; }
+
+extern "C" int upk_create(upk_ctx** out, int device) {
+  if (!out) return UPK_EINVAL;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return UPK_ENODEV;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return UPK_EHIP;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return UPK_ENODEV;  // CDNA4 only, no fallbacks
+  upk_ctx* c = new upk_ctx();
+  c->device = device;
+  c->num_cus = prop.multiProcessorCount;
+  c->err[0] = 0;
+  c->ws = nullptr;
+  c->ws_bytes = 0;
+  c->cfg_override = -1;
+  c->splitk_override = 0;
+  c->prof_on = 0;
+  for (int i = 0; i < UPK_NUM_CLASSES; ++i) {
+    c->prof_ms[i] = 0;
+    c->prof_n[i] = 0;
+  }
+  *out = c;
+  return UPK_OK;
+}
+
+extern "C" int upk_destroy(upk_ctx* ctx) {
+  if (!ctx) return UPK_EINVAL;
+  for (auto& r : ctx->recs) {
+    hipEventDestroy(r.e0);
+    hipEventDestroy(r.e1);
+  }
+  for (auto& r : ctx->free_recs) {
+    hipEventDestroy(r.e0);
+    hipEventDestroy(r.e1);
+  }
+  delete ctx;
+  return UPK_OK;
+}
+
+extern "C" const char* upk_last_error(upk_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+extern "C" int upk_set_workspace(upk_ctx* ctx, void* dptr, size_t bytes) {
+  if (!ctx) return UPK_EINVAL;
+  if (((uintptr_t)dptr) & 15) return upk_fail(ctx, UPK_EINVAL, "workspace must be 16-byte aligned");
+  ctx->ws = dptr;
+  ctx->ws_bytes = dptr ? bytes : 0;
+  return UPK_OK;
+}
+
+extern "C" int upk_num_cus(upk_ctx* ctx) { return ctx ? ctx->num_cus : 0; }
+
+// ------------------------------------------------------------------ weight packing
+namespace {
+
+__global__ void pack_weight_kernel(const float* w, int cout, int cin, int kh, int kw, const int* row_map,
+                                   int n_rows, const int* col_map, int cin_p, int n_pad, f16* out, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int j = (int)(idx & 31);
+  const long t = idx >> 5;
+  const int nrow = (int)(t % n_pad);
+  const int kc = (int)(t / n_pad);
+  const int k = kc * 32 + j;
+  const int tap = k / cin_p;
+  const int cip = k - tap * cin_p;
+  const int ky = tap / kw, kx = tap - ky * kw;
+  int ci = col_map ? col_map[cip] : (cip < cin ? cip : -1);
+  int o = -1;
+  if (nrow < n_rows) o = row_map ? row_map[nrow] : (nrow < cout ? nrow : -1);
+  float v = 0.f;
+  if (o >= 0 && o < cout && ci >= 0 && ci < cin) v = w[(((long)o * cin + ci) * kh + ky) * kw + kx];
+  out[idx] = (f16)v;
+}
+
+}  // namespace
+
+extern "C" size_t upk_packed_weight_bytes(int n_rows_packed, int cin_packed, int kh, int kw) {
+  const size_t n_pad = ((size_t)n_rows_packed + 15) & ~(size_t)15;
+  return n_pad * (size_t)cin_packed * kh * kw * sizeof(f16);
+}
+
+extern "C" int upk_pack_weight_f16(upk_ctx* ctx, const float* w, int cout, int cin, int kh, int kw,
+                                   const int32_t* row_map, int n_rows_packed, const int32_t* col_map,
+                                   int cin_packed, void* w_packed, upk_stream stream_) {
+  if (!ctx) return UPK_EINVAL;
+  if (!w || !w_packed) return upk_fail(ctx, UPK_EINVAL, "pack: null pointer");
+  if (cout <= 0 || cin <= 0 || kh <= 0 || kw <= 0 || n_rows_packed <= 0 || cin_packed <= 0 || (cin_packed & 31))
+    return upk_fail(ctx, UPK_EINVAL, "pack: cin_packed must be a positive multiple of 32");
+  if (!col_map && cin_packed < cin) return upk_fail(ctx, UPK_EINVAL, "pack: cin_packed < cin without col_map");
+  const int n_pad = (n_rows_packed + 15) & ~15;
+  const long total = (long)n_pad * cin_packed * kh * kw;
+  hipStream_t stream = (hipStream_t)stream_;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, w, cout, cin, kh,
+                     kw, row_map, n_rows_packed, col_map, cin_packed, n_pad, (f16*)w_packed, total);
+  return upk_check_launch(ctx, "pack_weight");
+}
+
+// ------------------------------------------------------------------ small ops
+namespace {
+
+// util.py:151-171: freqs = exp(-ln(max_period) * j / half) in fp32, args = t * freqs,
+// embedding = [cos | sin] (+ a zero column when dim is odd).
+__global__ void timestep_embed_kernel(const float* t, int n, int dim, float log_max_period, f16* out, int ld) {
+  const int i = blockIdx.x;
+  const int half = dim >> 1;
+  const float tv = t[i];
+  for (int j = threadIdx.x; j < ld; j += blockDim.x) {
+    float v = 0.f;
+    if (j < 2 * half) {
+      const int jj = (j < half) ? j : j - half;
+      const float f = expf(-log_max_period * (float)jj / (float)half);
+      const float arg = tv * f;
+      v = (j < half) ? cosf(arg) : sinf(arg);
+    }
+    out[(long)i * ld + j] = (f16)v;
+  }
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* x, int c, int hw, f16* y, int ldy, int c_off, int zero_to, float scale,
+                                    long total_pix) {
+  const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;  // b*hw + p
+  if (pix >= total_pix) return;
+  const long b = pix / hw;
+  const long p = pix - b * hw;
+  f16* yo = y + pix * ldy;
+  for (int ch = 0; ch < c; ++ch) yo[c_off + ch] = (f16)(x[(b * c + ch) * hw + p] * scale);
+  for (int ch = c_off + c; ch < zero_to; ++ch) yo[ch] = (f16)0.f;
+}
+
+__global__ void nhwc_to_nchw_kernel(const f16* x, int ldx, int c, int hw, float* y, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over b, c, p (p fastest)
+  if (idx >= total) return;
+  const long p = idx % hw;
+  const long t = idx / hw;
+  const long ch = t % c;
+  const long b = t / c;
+  y[idx] = (float)x[(b * hw + p) * ldx + ch];
+}
+
+__global__ void f32_to_f16_kernel(const float* x, int rows, int cols, f16* y, int ldy) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)rows * cols) return;
+  const long r = idx / cols;
+  const long cidx = idx - r * cols;
+  y[r * ldy + cidx] = (f16)x[idx];
+}
+
+// ddim.py:189-203 in one launch (see include/upk.h for the coefficient table).
+__global__ void ddim_step_kernel(float* x, const float* eps, const float* coefs, const float* noise, const int* step,
+                                 float* pred_x0, f16* xin, int ld_xin, int c, int hw, long n) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const int st = step ? *step : 0;
+  const float* cf = coefs + 4 * st;
+  const float c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
+  const float xv = x[idx], e = eps[idx];
+  const float p0 = (xv - c0 * e) * c1;
+  float xp = c2 * p0 + c3 * e;
+  if (noise) xp += noise[(long)st * n + idx];
+  x[idx] = xp;
+  if (pred_x0) pred_x0[idx] = p0;
+  if (xin) {
+    const long p = idx % hw;
+    const long t = idx / hw;
+    const long ch = t % c;
+    const long b = t / c;
+    xin[(b * hw + p) * ld_xin + ch] = (f16)xp;
+  }
+}
+
+__global__ void advance_step_kernel(int* step) { *step += 1; }
+
+}  // namespace
+
+extern "C" int upk_timestep_embed_f16(upk_ctx* ctx, const float* t, int n, int dim, float max_period, void* out,
+                                      int ld_out, upk_stream stream_) {
+  if (!ctx) return UPK_EINVAL;
+  if (!t || !out || n <= 0 || dim <= 1 || ld_out < dim) return upk_fail(ctx, UPK_EINVAL, "timestep_embed: bad args");
+  upk_prof_scope prof(ctx, UPK_CLS_OTHER, (hipStream_t)stream_);
+  hipLaunchKernelGGL(timestep_embed_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream_, t, n, dim, logf(max_period),
+                     (f16*)out, ld_out);
+  return upk_check_launch(ctx, "timestep_embed");
+}
+
+extern "C" int upk_nchw_f32_to_nhwc_f16(upk_ctx* ctx, const float* x, int batch, int c, int hw, void* y, int ldy,
+                                        int c_off, int zero_pad_to, float scale, upk_stream stream_) {
+  if (!ctx) return UPK_EINVAL;
+  if (!x || !y || batch <= 0 || c <= 0 || hw <= 0 || c_off < 0 || c_off + c > ldy || zero_pad_to > ldy)
+    return upk_fail(ctx, UPK_EINVAL, "nchw_to_nhwc: bad args");
+  const long total = (long)batch * hw;
+  upk_prof_scope prof(ctx, UPK_CLS_OTHER, (hipStream_t)stream_);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x,
+                     c, hw, (f16*)y, ldy, c_off, zero_pad_to, scale, total);
+  return upk_check_launch(ctx, "nchw_to_nhwc");
+}
+
+extern "C" int upk_nhwc_f16_to_nchw_f32(upk_ctx* ctx, const void* x, int ldx, int batch, int c, int hw, float* y,
+                                        upk_stream stream_) {
+  if (!ctx) return UPK_EINVAL;
+  if (!x || !y || batch <= 0 || c <= 0 || hw <= 0 || ldx < c) return upk_fail(ctx, UPK_EINVAL, "nhwc_to_nchw: bad args");
+  const long total = (long)batch * c * hw;
+  upk_prof_scope prof(ctx, UPK_CLS_OTHER, (hipStream_t)stream_);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
+                     (const f16*)x, ldx, c, hw, y, total);
+  return upk_check_launch(ctx, "nhwc_to_nchw");
+}
+
+extern "C" int upk_f32_to_f16(upk_ctx* ctx, const float* x, int rows, int cols, void* y, int ldy, upk_stream stream_) {
+  if (!ctx) return UPK_EINVAL;
+  if (!x || !y || rows <= 0 || cols <= 0 || ldy < cols) return upk_fail(ctx, UPK_EINVAL, "f32_to_f16: bad args");
+  const long total = (long)rows * cols;
+  upk_prof_scope prof(ctx, UPK_CLS_OTHER, (hipStream_t)stream_);
+  hipLaunchKernelGGL(f32_to_f16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x,
+                     rows, cols, (f16*)y, ldy);
+  return upk_check_launch(ctx, "f32_to_f16");
+}
+
+extern "C" int upk_ddim_step_f32(upk_ctx* ctx, float* x, const float* eps, const float* coefs, const float* noise,
+                                 const int32_t* step, float* pred_x0, void* xin, int ld_xin, int batch, int c, int hw,
+                                 upk_stream stream_) {
+  if (!ctx) return UPK_EINVAL;
+  if (!x || !eps || !coefs || batch <= 0 || c <= 0 || hw <= 0) return upk_fail(ctx, UPK_EINVAL, "ddim_step: bad args");
+  if (xin && ld_xin < c) return upk_fail(ctx, UPK_EINVAL, "ddim_step: ld_xin < c");
+  const long n = (long)batch * c * hw;
+  upk_prof_scope prof(ctx, UPK_CLS_OTHER, (hipStream_t)stream_);
+  hipLaunchKernelGGL(ddim_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x, eps,
+                     coefs, noise, step, pred_x0, (f16*)xin, ld_xin, c, hw, n);
+  return upk_check_launch(ctx, "ddim_step");
+}
+
+extern "C" int upk_advance_step(upk_ctx* ctx, int32_t* step, upk_stream stream_) {
+  if (!ctx || !step) return UPK_EINVAL;
+  hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, step);
+  return upk_check_launch(ctx, "advance_step");
+}
+
+// ------------------------------------------------------------------ HIP graphs
+struct upk_graph {
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+};
+
+extern "C" int upk_graph_begin(upk_ctx* ctx, upk_stream stream) {
+  if (!ctx) return UPK_EINVAL;
+  if (ctx->prof_on) return upk_fail(ctx, UPK_EINVAL, "graph capture with profiling enabled");
+  UPK_HIP(ctx, hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+  return UPK_OK;
+}
+
+extern "C" int upk_graph_end(upk_ctx* ctx, upk_stream stream, upk_graph** out) {
+  if (!ctx || !out) return UPK_EINVAL;
+  *out = nullptr;
+  hipGraph_t g = nullptr;
+  UPK_HIP(ctx, hipStreamEndCapture((hipStream_t)stream, &g));
+  hipGraphExec_t e = nullptr;
+  hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+  if (err != hipSuccess) {
+    hipGraphDestroy(g);
+    return upk_fail(ctx, UPK_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(err));
+  }
+  upk_graph* h = new upk_graph();
+  h->graph = g;
+  h->exec = e;
+  *out = h;
+  return UPK_OK;
+}
+
+extern "C" int upk_graph_launch(upk_ctx* ctx, upk_graph* g, upk_stream stream) {
+  if (!ctx || !g) return UPK_EINVAL;
+  UPK_HIP(ctx, hipGraphLaunch(g->exec, (hipStream_t)stream));
+  return UPK_OK;
+}
+
+extern "C" int upk_graph_destroy(upk_ctx* ctx, upk_graph* g) {
+  if (!g) return UPK_EINVAL;
+  hipGraphExecDestroy(g->exec);
+  hipGraphDestroy(g->graph);
+  delete g;
+  return UPK_OK;
+}
+
+// ------------------------------------------------------------------ profiling
+extern "C" int upk_prof_enable(upk_ctx* ctx, int on) {
+  if (!ctx) return UPK_EINVAL;
+  ctx->prof_on = on ? 1 : 0;
+  return UPK_OK;
+}
+
+extern "C" int upk_prof_collect(upk_ctx* ctx, double* ms_host, long long* launches_host) {
+  if (!ctx || !ms_host || !launches_host) return UPK_EINVAL;
+  for (auto& r : ctx->recs) {
+    UPK_HIP(ctx, hipEventSynchronize(r.e1));
+    float ms = 0.f;
+    UPK_HIP(ctx, hipEventElapsedTime(&ms, r.e0, r.e1));
+    ctx->prof_ms[r.cls] += ms;
+    ctx->prof_n[r.cls] += 1;
+    ctx->free_recs.push_back(r);
+  }
+  ctx->recs.clear();
+  for (int i = 0; i < UPK_NUM_CLASSES; ++i) {
+    ms_host[i] = ctx->prof_ms[i];
+    launches_host[i] = ctx->prof_n[i];
+    ctx->prof_ms[i] = 0;
+    ctx->prof_n[i] = 0;
+  }
+  return UPK_OK;
+}

@@ -1,0 +1,272 @@
+// GroupNorm(+SiLU) and LayerNorm for gfx950 — HBM/L2-bound wavefront-reduction kernels,
+// fp32 statistics (GroupNorm32 computes in fp32: util.py:214-216).
+//
+// GroupNorm on NHWC: a group's channels are contiguous per pixel but a group spans every
+// pixel, so statistics are taken in two coalesced stages:
+//   1. gn_stats: grid (chunks, B); each block streams [pixels of its chunk] x [all C
+//      channels] with 16-byte loads, every thread owning a fixed 8-channel vector, and
+//      folds its per-channel (sum, sumsq) into the 32 groups through LDS;
+//      writes partial[b][chunk][group][2] (deterministic, no global atomics).
+//   2. gn_apply: every block first reduces the <=64 chunk partials of its sample into
+//      per-channel scale/shift tables in LDS, then streams y = act(x*scale + shift).
+// The input may be a two-source channel concat (openaimodel.py:736): groups may straddle
+// the seam (e.g. 896+448 channels -> 42-wide groups), which the per-channel fold handles.
+#include "common.h"
+
+namespace {
+
+constexpr int GN_MAX_CHUNKS = 64;
+constexpr int GN_GROUPS_MAX = 32;
+
+struct GnArgs {
+  const f16* x1;
+  const f16* x2;
+  int c1, c2, ld1, ld2;
+  int hw, groups, cpg;
+  int nchunks, pix_per_chunk;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  int silu;
+  f16* y;
+  int ldy;
+  float* ws;  // [B][nchunks][groups][2]
+};
+
+__device__ __forceinline__ f16x8 gn_load(const GnArgs& a, long pix, int v) {
+  const int ch = v * 8;
+  if (ch < a.c1) return *(const f16x8*)(a.x1 + pix * a.ld1 + ch);
+  return *(const f16x8*)(a.x2 + pix * a.ld2 + (ch - a.c1));
+}
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a) {
+  // per-(row slot, channel) partial sums; folded in a FIXED order below so that the
+  // statistics (and everything downstream) are bitwise reproducible run to run.
+  __shared__ float sc[2][256 * 8];
+  const int C = a.c1 + a.c2;
+  const int vpr = C >> 3;  // 16-byte vectors per pixel; vpr <= 256 (C <= 2048)
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int p0 = chunk * a.pix_per_chunk;
+  const int p1 = min(a.hw, p0 + a.pix_per_chunk);
+  // thread layout: vpr threads cover the vectors of one pixel, rpi pixels in flight.
+  const int rpi = 256 / vpr;
+  const int r = tid / vpr;
+  const int v = tid - r * vpr;
+  if (r < rpi) {
+    float s[8], ss[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
+    for (int p = p0 + r; p < p1; p += rpi) {
+      const f16x8 xv = gn_load(a, (long)b * a.hw + p, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = (float)xv[j];
+        s[j] += f;
+        ss[j] += f * f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sc[0][r * C + v * 8 + j] = s[j];
+      sc[1][r * C + v * 8 + j] = ss[j];
+    }
+  }
+  __syncthreads();
+  // 64 threads: (group, sum|sumsq); a group may straddle vectors and the concat seam.
+  if (tid < a.groups * 2) {
+    const int g = tid >> 1, which = tid & 1;
+    float t = 0.f;
+    for (int rr = 0; rr < rpi; ++rr)
+      for (int ch = g * a.cpg; ch < (g + 1) * a.cpg; ++ch) t += sc[which][rr * C + ch];
+    a.ws[((long)(b * a.nchunks + chunk) * a.groups) * 2 + tid] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float tab[];  // scale[C], shift[C]
+  __shared__ float smean[GN_GROUPS_MAX], srstd[GN_GROUPS_MAX];
+  const int C = a.c1 + a.c2;
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x;
+  if (tid < a.groups) {
+    // fixed-order reduction over chunks: bitwise reproducible
+    double s = 0.0, ss = 0.0;
+    const float* w = a.ws + ((long)b * a.nchunks * a.groups + tid) * 2;
+    for (int k = 0; k < a.nchunks; ++k) {
+      s += w[(long)k * a.groups * 2];
+      ss += w[(long)k * a.groups * 2 + 1];
+    }
+    const double n = (double)a.hw * a.cpg;
+    const double mean = s / n;
+    double var = ss / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    smean[tid] = (float)mean;
+    srstd[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
+  }
+  __syncthreads();
+  float* scale = tab;
+  float* shift = tab + C;
+  for (int ch = tid; ch < C; ch += 256) {
+    const int g = ch / a.cpg;
+    const float sc = srstd[g] * a.gamma[ch];
+    scale[ch] = sc;
+    shift[ch] = a.beta[ch] - smean[g] * sc;
+  }
+  __syncthreads();
+  const int vpr = C >> 3;
+  const int p0 = blockIdx.x * rows_per_block;
+  const int p1 = min(a.hw, p0 + rows_per_block);
+  const int nvec = (p1 - p0) * vpr;
+  for (int i = tid; i < nvec; i += 256) {
+    const int pr = i / vpr;
+    const int v = i - pr * vpr;
+    const long pix = (long)b * a.hw + p0 + pr;
+    const f16x8 xv = gn_load(a, pix, v);
+    const f32x4 sc0 = *(const f32x4*)(scale + v * 8), sc1 = *(const f32x4*)(scale + v * 8 + 4);
+    const f32x4 sh0 = *(const f32x4*)(shift + v * 8), sh1 = *(const f32x4*)(shift + v * 8 + 4);
+    f16x8 yv;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = (float)xv[j] * (j < 4 ? sc0[j] : sc1[j - 4]) + (j < 4 ? sh0[j] : sh1[j - 4]);
+      if (a.silu) f = upk_silu(f);
+      yv[j] = (f16)f;
+    }
+    *(f16x8*)(a.y + pix * a.ldy + v * 8) = yv;
+  }
+}
+
+// One wave per row; the row lives in registers (d <= 2048), exact two-pass mean/variance.
+template <int VPL>  // 16-byte vectors per lane
+__global__ __launch_bounds__(256) void layernorm_kernel(const f16* x, int ldx, int rows, int d, const float* gamma,
+                                                        const float* beta, float eps, f16* y, int ldy) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nv = d >> 3;
+  const f16* xr = x + (long)row * ldx;
+  f16x8 xv[VPL];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int v = lane + i * 64;
+    if (v < nv) {
+      xv[i] = *(const f16x8*)(xr + v * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (float)xv[i][j];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int v = lane + i * 64;
+    if (v < nv) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = (float)xv[i][j] - mean;
+        q += f * f;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = rsqrtf(q / d + eps);
+  f16* yr = y + (long)row * ldy;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int v = lane + i * 64;
+    if (v < nv) {
+      const f32x4 g0 = *(const f32x4*)(gamma + v * 8), g1 = *(const f32x4*)(gamma + v * 8 + 4);
+      const f32x4 b0 = *(const f32x4*)(beta + v * 8), b1 = *(const f32x4*)(beta + v * 8 + 4);
+      f16x8 yv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = ((float)xv[i][j] - mean) * rstd;
+        yv[j] = (f16)(f * (j < 4 ? g0[j] : g1[j - 4]) + (j < 4 ? b0[j] : b1[j - 4]));
+      }
+      *(f16x8*)(yr + v * 8) = yv;
+    }
+  }
+}
+
+inline int gn_chunks(int hw) {
+  int n = (hw + 31) / 32;
+  if (n > GN_MAX_CHUNKS) n = GN_MAX_CHUNKS;
+  if (n < 1) n = 1;
+  return n;
+}
+
+}  // namespace
+
+extern "C" size_t upk_groupnorm_ws_bytes(int batch, int hw) {
+  return (size_t)batch * gn_chunks(hw) * GN_GROUPS_MAX * 2 * sizeof(float);
+}
+
+extern "C" int upk_groupnorm_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* x2, int c2, int ld2,
+                                      int batch, int hw, int groups, const float* gamma, const float* beta,
+                                      float eps, int fuse_silu, void* y, int ldy, float* stats_ws,
+                                      upk_stream stream_) {
+  if (!ctx) return UPK_EINVAL;
+  if (!x1 || !gamma || !beta || !y || !stats_ws) return upk_fail(ctx, UPK_EINVAL, "groupnorm: null pointer");
+  const int C = c1 + c2;
+  if (c1 <= 0 || c2 < 0 || (c1 & 7) || (c2 & 7) || (c2 && !x2) || (ld1 & 7) || (c2 && (ld2 & 7)) || (ldy & 7))
+    return upk_fail(ctx, UPK_EINVAL, "groupnorm: channels / leading dims must be multiples of 8");
+  if (groups <= 0 || groups > GN_GROUPS_MAX || C % groups || C > 2048)
+    return upk_fail(ctx, UPK_ESHAPE, "groupnorm: C=%d groups=%d unsupported", C, groups);
+  if (batch <= 0 || hw <= 0) return upk_fail(ctx, UPK_EINVAL, "groupnorm: empty");
+  hipStream_t stream = (hipStream_t)stream_;
+  GnArgs a;
+  a.x1 = (const f16*)x1;
+  a.x2 = (const f16*)x2;
+  a.c1 = c1;
+  a.c2 = c2;
+  a.ld1 = ld1;
+  a.ld2 = ld2;
+  a.hw = hw;
+  a.groups = groups;
+  a.cpg = C / groups;
+  a.nchunks = gn_chunks(hw);
+  a.pix_per_chunk = (hw + a.nchunks - 1) / a.nchunks;
+  a.nchunks = (hw + a.pix_per_chunk - 1) / a.pix_per_chunk;
+  a.gamma = gamma;
+  a.beta = beta;
+  a.eps = eps;
+  a.silu = fuse_silu;
+  a.y = (f16*)y;
+  a.ldy = ldy;
+  a.ws = stats_ws;
+  upk_prof_scope prof(ctx, UPK_CLS_GN, stream);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nchunks, batch), dim3(256), 0, stream, a);
+  int rc = upk_check_launch(ctx, "gn_stats");
+  if (rc) return rc;
+  // apply: ~16 KB of fp16 per block
+  int rows = (8192 + C - 1) / C;
+  if (rows < 1) rows = 1;
+  const int blocks = (hw + rows - 1) / rows;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, batch), dim3(256), (size_t)C * 2 * sizeof(float), stream, a, rows);
+  return upk_check_launch(ctx, "gn_apply");
+}
+
+extern "C" int upk_layernorm_f16(upk_ctx* ctx, const void* x, int ldx, int rows, int d, const float* gamma,
+                                 const float* beta, float eps, void* y, int ldy, upk_stream stream_) {
+  if (!ctx) return UPK_EINVAL;
+  if (!x || !gamma || !beta || !y) return upk_fail(ctx, UPK_EINVAL, "layernorm: null pointer");
+  if (rows <= 0 || d <= 0 || (d & 7) || (ldx & 7) || (ldy & 7) || d > 2048)
+    return upk_fail(ctx, UPK_ESHAPE, "layernorm: d=%d must be a multiple of 8 and <= 2048", d);
+  hipStream_t stream = (hipStream_t)stream_;
+  const int nv = d >> 3;
+  dim3 grid((rows + 3) / 4), block(256);
+  upk_prof_scope prof(ctx, UPK_CLS_LN, stream);
+  const f16* xp = (const f16*)x;
+  f16* yp = (f16*)y;
+  if (nv <= 64)
+    hipLaunchKernelGGL((layernorm_kernel<1>), grid, block, 0, stream, xp, ldx, rows, d, gamma, beta, eps, yp, ldy);
+  else if (nv <= 128)
+    hipLaunchKernelGGL((layernorm_kernel<2>), grid, block, 0, stream, xp, ldx, rows, d, gamma, beta, eps, yp, ldy);
+  else
+    hipLaunchKernelGGL((layernorm_kernel<4>), grid, block, 0, stream, xp, ldx, rows, d, gamma, beta, eps, yp, ldy);
+  return upk_check_launch(ctx, "layernorm");
+}
