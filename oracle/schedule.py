@@ -41,14 +41,23 @@ def ddim_timesteps(num_ddim, num_ddpm=1000, method="uniform"):
 def ddim_parameters(alphas_cumprod_f32, timesteps, eta):
     """util.py:63-74 applied to the fp32 alphas_cumprod buffer (ddim.py:43-45).
 
-    alphas keeps the buffer dtype (fp32); alphas_prev and sigmas become float64 because
-    the reference builds them from a python list / numpy sqrt.  alphas_prev[0] is
-    alphas_cumprod[0], not 1.0 (util.py:66)."""
-    a = np.asarray(alphas_cumprod_f32, dtype=np.float32)
-    alphas = a[timesteps]
-    alphas_prev = np.asarray([a[0]] + a[timesteps[:-1]].tolist())
-    sigmas = eta * np.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
-    return sigmas, alphas, alphas_prev
+    In the reference `alphas` is an fp32 torch tensor and `alphas_prev` a float64 numpy
+    array, so the sigma expression is evaluated with torch's mixed dispatch:
+      (1 - alphas_prev) / (1 - alphas)  ->  Tensor.__rtruediv__  =  (1 - alphas).reciprocal() [fp32] * f64
+      alphas / alphas_prev              ->  fp32 tensor / f64      =  f64
+    That order is restated explicitly here (bit-exact with the reference, which matters
+    only at the 1e-8 level).  alphas_prev[0] is alphas_cumprod[0], not 1.0 (util.py:66)."""
+    import torch
+    a32 = torch.as_tensor(np.asarray(alphas_cumprod_f32, dtype=np.float32))
+    ts = np.asarray(timesteps)
+    alphas = a32[torch.as_tensor(ts, dtype=torch.long)]
+    alphas_prev = np.asarray([float(a32[0])] + a32[torch.as_tensor(ts[:-1], dtype=torch.long)].tolist())
+    ap = torch.from_numpy(alphas_prev)
+    recip = (1 - alphas).reciprocal()                  # fp32
+    t1 = recip.double() * (1 - ap)                     # f64
+    t2 = 1 - alphas.double() / ap                      # f64
+    sigmas = eta * torch.sqrt(t1 * t2)
+    return sigmas.numpy(), alphas.numpy(), alphas_prev
 
 
 def ddim_step_coefficients(alphas_cumprod_f32, S, eta, num_ddpm=1000, method="uniform"):
