@@ -1,0 +1,2 @@
+"""ldm.models.autoencoder -> upgpt_amd.vae."""
+from upgpt_amd.vae import AutoencoderKL  # noqa: F401

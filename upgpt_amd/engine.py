@@ -1,0 +1,638 @@
+"""Lowers arch.* records + fp32 master weights to flat programs of libupk.so launches.
+
+Design (MI355X-first, not a translation of the reference's nn.Module.forward chain):
+  * activations live as token-major NHWC fp16 [B*H*W, C] for the whole network, so
+    conv1x1 == Linear == GEMM and the reference's `b c h w <-> b (h w) c` rearranges
+    (attention.py:256,259) and head split/merge copies (:178,192) do not exist;
+  * channel concats (openaimodel.py:736) are never materialised — GroupNorm and the
+    implicit-GEMM kernel read two sources; nearest-2x upsampling is folded into the
+    following conv's addressing; bias / timestep-embedding add / residual / GEGLU / SiLU
+    are GEMM epilogues;
+  * shapes are static per (B, H, W, n_ctx): every buffer is allocated once, every launch
+    descriptor is built once, and the per-step program is captured into ONE HIP graph that
+    the sampler replays S times; the step index lives on the device (no per-step host
+    work, no torch.full allocations as in ddim.py:189-192);
+  * step-invariant work is hoisted out of the loop: the timestep-embedding MLP and all 22
+    emb_layers projections for ALL S steps (one batched GEMM each) and the cross-attention
+    K / V projections of the context.
+
+PyTorch here = device allocator + stream handle only.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .arch import UNetArch, VAEArch
+
+
+def _rup(v, m):
+    return (v + m - 1) // m * m
+
+
+def head_pad(d):
+    for p in (32, 64, 128, 256, 512):
+        if d <= p:
+            return p
+    raise NotImplementedError("attention head dim %d > 512" % d)
+
+
+class Act:
+    """[B*H*W, ld] fp16 activation (C valid channels)."""
+    __slots__ = ("t", "B", "H", "W", "C")
+
+    def __init__(self, t, B, H, W, C):
+        self.t, self.B, self.H, self.W, self.C = t, B, H, W, C
+
+    @property
+    def ld(self):
+        return self.t.shape[-1]
+
+    @property
+    def M(self):
+        return self.B * self.H * self.W
+
+
+class PW:
+    """A packed weight: fp16 tiles + fp32 bias in packed row order."""
+    __slots__ = ("w", "n_pad", "bias", "n_out", "k_packed", "ksize", "n_real", "k_real")
+
+
+class Packer:
+    """fp32 OIHW / [out,in] master weights -> libupk packed fp16 (done once per weight set)."""
+
+    def __init__(self, ctx, get):
+        self.ctx, self.get, self.dev = ctx, get, ctx.device
+
+    def _maps(self, m):
+        return None if m is None else torch.as_tensor(m, dtype=torch.int32, device=self.dev).contiguous()
+
+    def pack(self, names, row_map=None, col_map=None, cin_packed=None, bias=True, n_out=None):
+        """`names`: one weight name or a list whose rows are concatenated (fused q|k|v)."""
+        if isinstance(names, str):
+            names = [names]
+        ws = [self.get(n + ".weight") for n in names]
+        w = ws[0] if len(ws) == 1 else torch.cat([x.reshape(x.shape[0], -1) for x in ws], 0).reshape(
+            -1, *ws[0].shape[1:])
+        w = w.contiguous().float()
+        rm, cm = self._maps(row_map), self._maps(col_map)
+        p = PW()
+        p.w, p.n_pad = self.ctx.pack_weight(w, row_map=rm, col_map=cm, cin_packed=cin_packed)
+        p.ksize = w.shape[-1] if w.dim() == 4 else 1
+        cin = w.shape[1]
+        p.k_packed = (cin_packed if cin_packed is not None else _rup(cin if cm is None else cm.numel(), 32))
+        n_rows = w.shape[0] if rm is None else rm.numel()
+        p.n_out = n_rows if n_out is None else n_out
+        p.n_real = w.shape[0] if rm is None else int((rm >= 0).sum().item())
+        p.k_real = (cin if cm is None else int((cm >= 0).sum().item())) * p.ksize * p.ksize
+        p.bias = None
+        if bias:
+            bs = [self.get(n + ".bias") for n in names]
+            b = (bs[0] if len(bs) == 1 else torch.cat(bs, 0)).float()
+            bp = torch.zeros(p.n_pad, dtype=torch.float32, device=self.dev)
+            if rm is None:
+                bp[: b.numel()] = b
+            else:
+                idx = rm.long()
+                bp[: idx.numel()] = torch.where(idx >= 0, b[idx.clamp(min=0)], torch.zeros((), device=self.dev))
+            p.bias = bp
+        return p
+
+    def vec(self, name):
+        return self.get(name).float().contiguous()
+
+
+def pad_rows_map(parts, heads, dh, dp):
+    """Row map of `parts` stacked [heads*dh]-row matrices -> [heads*dp]-row blocks each
+    (head dim zero-padded dh -> dp)."""
+    j = torch.arange(parts * heads * dp)
+    part, r = j // (heads * dp), j % (heads * dp)
+    h, d = r // dp, r % dp
+    return torch.where(d < dh, part * heads * dh + h * dh + d, torch.full_like(j, -1))
+
+
+def geglu_rows_map(inner):
+    """Per 64 packed rows: [32 value rows | 32 gate rows] (include/upk.h UPK_F_GEGLU)."""
+    j = torch.arange(2 * inner)
+    blk, r = j // 64, j % 64
+    return torch.where(r < 32, blk * 32 + r, inner + blk * 32 + (r - 32))
+
+
+class Program:
+    """A flat list of launches; each op is a callable taking the stream pointer."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.ops = []
+        self.keep = []
+        self.igemm_flops = 0
+        self.attn_flops = 0
+        self.n_launch = 0
+
+    def run(self, stream=None):
+        s = self.ctx._s() if stream is None else stream
+        for op in self.ops:
+            op(s)
+
+    def add(self, fn, *keep):
+        self.ops.append(fn)
+        self.keep.extend(keep)
+        self.n_launch += 1
+
+
+class Emitter:
+    """Shared emission helpers (conv / gemm / norms / attention) for both engines."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.h = ctx.h
+        self.dev = ctx.device
+        self.bufs = []
+
+    def alloc(self, *shape, dtype=torch.float16, zero=False):
+        t = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=self.dev)
+        self.bufs.append(t)
+        return t
+
+    def _chk(self, rc):
+        if rc != 0:
+            self.ctx._chk(rc)
+
+    def conv(self, P, x1, pw, *, x2=None, stride=1, flags=0, residual=None, rowvec=None, rv_bs=0, rv_ss=0,
+             step=None, out=None, vt=None, nchw_out=None, out_f32=None, spatial=None):
+        """Emits one upk_conv2d_nhwc_f16. Returns the output Act (fp16) unless nchw_out /
+        out_f32 is given."""
+        B, H, W = spatial if spatial is not None else (x1.B, x1.H, x1.W)
+        ks = pw.ksize
+        ups = bool(flags & L.F_UPSAMPLE2X)
+        HL, WL = (2 * H, 2 * W) if ups else (H, W)
+        if flags & L.F_PAD_ASYM:
+            Ho, Wo = (HL + 1 - 3) // 2 + 1, (WL + 1 - 3) // 2 + 1
+        else:
+            pad = 1 if ks == 3 else 0
+            Ho, Wo = (HL + 2 * pad - ks) // stride + 1, (WL + 2 * pad - ks) // stride + 1
+        M = B * Ho * Wo
+        d = L.ConvDesc()
+        d.x1 = x1.t.data_ptr()
+        d.c1 = _rup(x1.C, 32)
+        d.ld1 = x1.ld
+        if x2 is not None:
+            d.x2 = x2.t.data_ptr()
+            d.c2 = _rup(x2.C, 32)
+            d.ld2 = x2.ld
+        assert d.c1 + d.c2 == pw.k_packed, ("K mismatch", d.c1, d.c2, pw.k_packed)
+        assert d.c1 <= x1.ld and (x2 is None or d.c2 <= x2.ld)
+        d.batch, d.in_h, d.in_w = B, H, W
+        d.ksize, d.stride = ks, stride
+        d.w_packed = pw.w.data_ptr()
+        d.n_out, d.n_pad = pw.n_out, pw.n_pad
+        if pw.bias is not None:
+            d.bias = pw.bias.data_ptr()
+        if residual is not None:
+            d.residual = residual.t.data_ptr()
+            d.ld_res = residual.ld
+        if rowvec is not None:
+            d.rowvec = rowvec.data_ptr()
+            d.rv_batch_stride, d.rv_step_stride = rv_bs, rv_ss
+        if step is not None:
+            d.step = step.data_ptr()
+        ret = None
+        if nchw_out is not None:
+            d.y = nchw_out.data_ptr()
+            d.ldy = 0
+            flags |= L.F_OUT_NCHW_F32
+        elif out_f32 is not None:
+            d.y = out_f32.data_ptr()
+            d.ldy = out_f32.shape[-1]
+            flags |= L.F_OUT_F32
+        else:
+            if out is None:
+                ld = pw.n_out if pw.n_out % 8 == 0 else _rup(pw.n_out, 32)
+                out = Act(self.alloc(M, ld, zero=(ld != pw.n_out)), B, Ho, Wo, pw.n_out)
+            d.y = out.t.data_ptr()
+            d.ldy = out.ld
+            ret = out
+        if vt is not None:
+            d.vt = vt["t"].data_ptr()
+            d.vt_from, d.vt_heads, d.vt_dhead = vt["from"], vt["heads"], vt["dhead"]
+            d.vt_ld, d.vt_tokens = vt["ld"], vt["tokens"]
+        d.flags = flags
+        fn, h, ref = self.lib.upk_conv2d_nhwc_f16, self.h, C.byref(d)
+        chk = self._chk
+        P.add(lambda s: chk(fn(h, ref, s)), d, pw, x1, x2, residual, rowvec, out, nchw_out, out_f32, vt)
+        P.igemm_flops += 2 * M * pw.n_real * pw.k_real
+        return ret
+
+    def groupnorm(self, P, x1, gamma, beta, eps, silu, ws, x2=None):
+        Cc = x1.C + (x2.C if x2 is not None else 0)
+        y = Act(self.alloc(x1.M, Cc), x1.B, x1.H, x1.W, Cc)
+        fn, h, chk = self.lib.upk_groupnorm_nhwc_f16, self.h, self._chk
+        a = (x1.t.data_ptr(), x1.C, x1.ld, x2.t.data_ptr() if x2 is not None else None, x2.C if x2 is not None else 0,
+             x2.ld if x2 is not None else 0, x1.B, x1.H * x1.W, 32, gamma.data_ptr(), beta.data_ptr(), float(eps),
+             int(bool(silu)), y.t.data_ptr(), y.ld, ws.data_ptr())
+        P.add(lambda s: chk(fn(h, *a, s)), x1, x2, gamma, beta, y, ws)
+        P.n_launch += 1  # stats + apply
+        return y
+
+    def layernorm(self, P, x, gamma, beta, eps=1e-5):
+        y = Act(self.alloc(x.M, x.C), x.B, x.H, x.W, x.C)
+        fn, h, chk = self.lib.upk_layernorm_f16, self.h, self._chk
+        a = (x.t.data_ptr(), x.ld, x.M, x.C, gamma.data_ptr(), beta.data_ptr(), float(eps), y.t.data_ptr(), y.ld)
+        P.add(lambda s: chk(fn(h, *a, s)), x, gamma, beta, y)
+        return y
+
+    def attention(self, P, q, ldq, qbs, k, ldk, kbs, vt, vt_ld, out, ldo, obs, B, heads, nq, nkv, dp, scale):
+        fn, h, chk = self.lib.upk_attention_f16, self.h, self._chk
+        a = (q.data_ptr(), ldq, qbs, k.data_ptr(), ldk, kbs, vt.data_ptr(), vt_ld, out.data_ptr(), ldo, obs, B, heads,
+             nq, nkv, dp, float(scale))
+        P.add(lambda s: chk(fn(h, *a, s)), q, k, vt, out)
+
+
+# ====================================================================== UNet
+class PackedUNet:
+    """All UNet weights packed for the kernels (independent of batch / resolution)."""
+
+    def __init__(self, ctx, arch: UNetArch, get):
+        pk = Packer(ctx, get)
+        self.arch = arch
+        mc, te = arch.model_channels, arch.time_embed_dim
+        if mc % 32:
+            raise NotImplementedError("model_channels must be a multiple of 32 (got %d)" % mc)
+        w = {}
+        w["time_embed.0"] = pk.pack("time_embed.0")
+        w["time_embed.2"] = pk.pack("time_embed.2")
+        v = {}
+
+        def norm(name):
+            v[name] = (pk.vec(name + ".weight"), pk.vec(name + ".bias"))
+
+        for Lr in arch.all_layers():
+            n = Lr.name
+            if Lr.kind == "conv":
+                w[n] = pk.pack(n, cin_packed=_rup(Lr.cin, 32))
+            elif Lr.kind == "res":
+                norm(n + ".in_layers.0")
+                w[n + ".in_layers.2"] = pk.pack(n + ".in_layers.2")
+                w[n + ".emb_layers.1"] = pk.pack(n + ".emb_layers.1")
+                norm(n + ".out_layers.0")
+                w[n + ".out_layers.3"] = pk.pack(n + ".out_layers.3")
+                if Lr.cin != Lr.cout:
+                    w[n + ".skip_connection"] = pk.pack(n + ".skip_connection")
+            elif Lr.kind == "st":
+                if Lr.depth != 1:
+                    raise NotImplementedError("transformer_depth != 1")
+                heads, dh = Lr.heads, Lr.dhead
+                dp = head_pad(dh)
+                hd = heads * dp
+                norm(n + ".norm")
+                w[n + ".proj_in"] = pk.pack(n + ".proj_in")
+                t = n + ".transformer_blocks.0"
+                to_out_cols = pad_rows_map(1, heads, dh, dp)
+                w[t + ".attn1.qkv"] = pk.pack([t + ".attn1.to_q", t + ".attn1.to_k", t + ".attn1.to_v"],
+                                              row_map=pad_rows_map(3, heads, dh, dp), bias=False, n_out=2 * hd)
+                w[t + ".attn1.to_out"] = pk.pack(t + ".attn1.to_out.0", col_map=to_out_cols)
+                w[t + ".attn2.q"] = pk.pack(t + ".attn2.to_q", row_map=pad_rows_map(1, heads, dh, dp), bias=False)
+                w[t + ".attn2.kv"] = pk.pack([t + ".attn2.to_k", t + ".attn2.to_v"],
+                                             row_map=pad_rows_map(2, heads, dh, dp), bias=False, n_out=hd)
+                w[t + ".attn2.to_out"] = pk.pack(t + ".attn2.to_out.0", col_map=to_out_cols)
+                inner = heads * dh
+                w[t + ".ff.geglu"] = pk.pack(t + ".ff.net.0.proj", row_map=geglu_rows_map(4 * inner), n_out=4 * inner)
+                w[t + ".ff.out"] = pk.pack(t + ".ff.net.2")
+                for k in ("norm1", "norm2", "norm3"):
+                    norm(t + "." + k)
+                w[n + ".proj_out"] = pk.pack(n + ".proj_out")
+            elif Lr.kind == "down":
+                w[n + ".op"] = pk.pack(n + ".op")
+            elif Lr.kind == "up":
+                w[n + ".conv"] = pk.pack(n + ".conv")
+        norm("out.0")
+        w["out.2"] = pk.pack("out.2")
+        self.w, self.v = w, v
+
+
+class UNetPlan(Emitter):
+    """Buffers + programs of one UNet for fixed (B, H, W, n_ctx, rows).
+
+    rows = number of timestep-embedding rows: B in 'forward' mode (per-sample t, as
+    UNetModel.forward takes them), S in 'sampler' mode (one row per DDIM step, shared by
+    the batch: ddim.py:142 uses the same t for every sample)."""
+
+    def __init__(self, ctx, packed: PackedUNet, B, H, W, n_ctx, rows, mode):
+        super().__init__(ctx)
+        assert mode in ("forward", "sampler")
+        self.pk, self.arch = packed, packed.arch
+        self.B, self.H, self.W, self.n_ctx, self.rows, self.mode = B, H, W, n_ctx, rows, mode
+        a = self.arch
+        mc, te = a.model_channels, a.time_embed_dim
+        self.cin_pad = _rup(a.in_channels, 32)
+        # inputs / outputs
+        self.xin = Act(self.alloc(B * H * W, self.cin_pad, zero=True), B, H, W, a.in_channels)
+        self.ctx32 = self.alloc(B * n_ctx, a.context_dim, dtype=torch.float32)
+        self.ctx16 = Act(self.alloc(B * n_ctx, a.context_dim), 1, B * n_ctx, 1, a.context_dim)
+        self.t_rows = self.alloc(rows, dtype=torch.float32)
+        self.eps = self.alloc(B, a.out_channels, H, W, dtype=torch.float32)
+        self.step = self.alloc(1, dtype=torch.int32, zero=True)
+        self.gn_ws = self.alloc(max(64, ctx.groupnorm_ws_bytes(B, H * W) // 4), dtype=torch.float32)
+        self.rowvecs = {}
+        self.kv = {}
+        self.prep = Program(ctx)
+        self.body = Program(ctx)
+        self._emit_prep()
+        self._emit_body()
+
+    # ---- step-invariant part
+    def _emit_prep(self):
+        P, a, w = self.prep, self.arch, self.pk.w
+        mc, te, R = a.model_channels, a.time_embed_dim, self.rows
+        lib, h, chk = self.lib, self.h, self._chk
+        c32, c16 = self.ctx32, self.ctx16
+        P.add(lambda s: chk(lib.upk_f32_to_f16(h, c32.data_ptr(), c32.shape[0], c32.shape[1], c16.t.data_ptr(),
+                                               c16.ld, s)))
+        temb = Act(self.alloc(R, mc), 1, R, 1, mc)
+        tr = self.t_rows
+        P.add(lambda s: chk(lib.upk_timestep_embed_f16(h, tr.data_ptr(), R, mc, 10000.0, temb.t.data_ptr(), mc, s)))
+        # emb = Linear(SiLU(Linear(temb))) (openaimodel.py:506-511); every consumer applies SiLU
+        # first (openaimodel.py:219), so SiLU(emb) is what is kept.
+        h1 = self.conv(P, temb, w["time_embed.0"], flags=L.F_SILU)
+        semb = self.conv(P, h1, w["time_embed.2"], flags=L.F_SILU)
+        for Lr in a.all_layers():
+            if Lr.kind == "res":
+                rv = self.alloc(R, Lr.cout, dtype=torch.float32)
+                self.conv(P, semb, w[Lr.name + ".emb_layers.1"], out_f32=rv)
+                self.rowvecs[Lr.name] = rv
+            elif Lr.kind == "st":
+                heads, dp = Lr.heads, head_pad(Lr.dhead)
+                hd = heads * dp
+                vt_ld = _rup(self.n_ctx, 32)
+                kc = Act(self.alloc(self.B * self.n_ctx, hd), 1, self.B * self.n_ctx, 1, hd)
+                vtc = self.alloc(self.B, heads, dp, vt_ld, zero=True)
+                self.conv(P, self.ctx16, w[Lr.name + ".transformer_blocks.0.attn2.kv"], out=kc,
+                          vt=dict(t=vtc, heads=heads, dhead=dp, ld=vt_ld, tokens=self.n_ctx, **{"from": hd}))
+                self.kv[Lr.name] = (kc, vtc, vt_ld)
+
+    # ---- per-step part
+    def _rv(self, name):
+        rv = self.rowvecs[name]
+        if self.mode == "sampler":
+            return dict(rowvec=rv, rv_bs=0, rv_ss=rv.shape[1], step=self.step)
+        return dict(rowvec=rv, rv_bs=rv.shape[1], rv_ss=0, step=None)
+
+    def _res(self, P, Lr, x, skip):
+        w, v = self.pk.w, self.pk.v
+        n = Lr.name
+        g, b = v[n + ".in_layers.0"]
+        hN = self.groupnorm(P, x, g, b, 1e-5, True, self.gn_ws, x2=skip)
+        hh = self.conv(P, hN, w[n + ".in_layers.2"], **self._rv(n))
+        g, b = v[n + ".out_layers.0"]
+        hN = self.groupnorm(P, hh, g, b, 1e-5, True, self.gn_ws)
+        if Lr.cin != Lr.cout:
+            sk = self.conv(P, x, w[n + ".skip_connection"], x2=skip)
+        else:
+            assert skip is None
+            sk = x
+        return self.conv(P, hN, w[n + ".out_layers.3"], residual=sk)
+
+    def _st(self, P, Lr, x):
+        w, v = self.pk.w, self.pk.v
+        n = Lr.name
+        t = n + ".transformer_blocks.0"
+        B, HW, M = x.B, x.H * x.W, x.M
+        heads, dh = Lr.heads, Lr.dhead
+        dp = head_pad(dh)
+        hd = heads * dp
+        scale = dh ** -0.5
+        g, b = v[n + ".norm"]
+        xn = self.groupnorm(P, x, g, b, 1e-6, False, self.gn_ws)
+        t0 = self.conv(P, xn, w[n + ".proj_in"])
+        # self-attention
+        n1 = self.layernorm(P, t0, *v[t + ".norm1"])
+        qk = Act(self.alloc(M, 2 * hd), B, x.H, x.W, 2 * hd)
+        vt_ld = _rup(HW, 32)
+        vt = self.alloc(B, heads, dp, vt_ld, zero=True)
+        self.conv(P, n1, w[t + ".attn1.qkv"], out=qk,
+                  vt=dict(t=vt, heads=heads, dhead=dp, ld=vt_ld, tokens=HW, **{"from": 2 * hd}))
+        a1 = Act(self.alloc(M, hd), B, x.H, x.W, hd)
+        self.attention(P, qk.t, 2 * hd, HW * 2 * hd, qk.t[:, hd:], 2 * hd, HW * 2 * hd, vt, vt_ld, a1.t, hd, HW * hd,
+                       B, heads, HW, HW, dp, scale)
+        P.attn_flops += 4 * B * heads * HW * HW * dh
+        t1 = self.conv(P, a1, w[t + ".attn1.to_out"], residual=t0)
+        # cross-attention over the (precomputed) context K / V
+        n2 = self.layernorm(P, t1, *v[t + ".norm2"])
+        q2 = self.conv(P, n2, w[t + ".attn2.q"])
+        kc, vtc, cld = self.kv[n]
+        a2 = Act(self.alloc(M, hd), B, x.H, x.W, hd)
+        self.attention(P, q2.t, hd, HW * hd, kc.t, hd, self.n_ctx * hd, vtc, cld, a2.t, hd, HW * hd, B, heads, HW,
+                       self.n_ctx, dp, scale)
+        P.attn_flops += 4 * B * heads * HW * self.n_ctx * dh
+        t2 = self.conv(P, a2, w[t + ".attn2.to_out"], residual=t1)
+        # GEGLU feed-forward
+        n3 = self.layernorm(P, t2, *v[t + ".norm3"])
+        ff = self.conv(P, n3, w[t + ".ff.geglu"], flags=L.F_GEGLU)
+        t3 = self.conv(P, ff, w[t + ".ff.out"], residual=t2)
+        return self.conv(P, t3, w[n + ".proj_out"], residual=x)
+
+    def _layers(self, P, layers, x, skip=None):
+        w = self.pk.w
+        for Lr in layers:
+            if Lr.kind == "conv":
+                x = self.conv(P, x, w[Lr.name])
+            elif Lr.kind == "res":
+                x = self._res(P, Lr, x, skip)
+                skip = None
+            elif Lr.kind == "st":
+                x = self._st(P, Lr, x)
+            elif Lr.kind == "down":
+                x = self.conv(P, x, w[Lr.name + ".op"], stride=2)
+            elif Lr.kind == "up":
+                x = self.conv(P, x, w[Lr.name + ".conv"], flags=L.F_UPSAMPLE2X)
+        return x
+
+    def _emit_body(self):
+        P, a = self.body, self.arch
+        hs = []
+        x = self.xin
+        self.taps = {}  # block name -> Act (debug / parity tests)
+        for i, blk in enumerate(a.input_blocks):
+            x = self._layers(P, blk, x)
+            hs.append(x)
+            self.taps["input_blocks.%d" % i] = x
+        x = self._layers(P, a.middle_block, x)
+        self.taps["middle_block"] = x
+        for i, blk in enumerate(a.output_blocks):
+            x = self._layers(P, blk, x, skip=hs.pop())
+            self.taps["output_blocks.%d" % i] = x
+        g, b = self.pk.v["out.0"]
+        xn = self.groupnorm(P, x, g, b, 1e-5, True, self.gn_ws)
+        self.conv(P, xn, self.pk.w["out.2"], nchw_out=self.eps)
+
+    # ---- host-facing helpers
+    def load_context(self, context):
+        """context: [B, n_ctx, context_dim] tensor (any float dtype / device)."""
+        assert tuple(context.shape) == (self.B, self.n_ctx, self.arch.context_dim), \
+            "context shape %s != plan %s" % (tuple(context.shape), (self.B, self.n_ctx, self.arch.context_dim))
+        self.ctx32.copy_(context.reshape(self.B * self.n_ctx, -1).to(self.dev, torch.float32), non_blocking=True)
+
+    def load_x_nchw(self, x, c_off=0, zero_pad_to=0):
+        """fp32 NCHW [B, c, H, W] -> channels [c_off, c_off + c) of the stem input."""
+        x = x.to(self.dev, torch.float32).contiguous()
+        assert x.shape[0] == self.B and tuple(x.shape[2:]) == (self.H, self.W)
+        self.ctx.nchw_to_nhwc(x, self.B, x.shape[1], self.H * self.W, self.xin.t, self.xin.ld, c_off, zero_pad_to, 1.0)
+
+
+# ====================================================================== VAE decoder
+class PackedVAEDecoder:
+    def __init__(self, ctx, arch: VAEArch, get):
+        pk = Packer(ctx, get)
+        self.arch = arch
+        w, v = {}, {}
+
+        def norm(name):
+            v[name] = (pk.vec("decoder." + name + ".weight"), pk.vec("decoder." + name + ".bias"))
+
+        w["post_quant_conv"] = pk.pack("post_quant_conv", cin_packed=_rup(arch.embed_dim, 32))
+        for Lr in arch.decoder:
+            n, d = Lr.name, "decoder." + Lr.name
+            if Lr.kind in ("conv", "conv_out"):
+                w[n] = pk.pack(d, cin_packed=_rup(Lr.cin, 32))
+            elif Lr.kind == "resnet":
+                norm(n + ".norm1")
+                w[n + ".conv1"] = pk.pack(d + ".conv1")
+                norm(n + ".norm2")
+                w[n + ".conv2"] = pk.pack(d + ".conv2")
+                if Lr.cin != Lr.cout:
+                    w[n + ".nin_shortcut"] = pk.pack(d + ".nin_shortcut")
+            elif Lr.kind == "attn":
+                if Lr.ch not in (32, 64, 128, 256, 512):
+                    raise NotImplementedError("VAE AttnBlock width %d" % Lr.ch)
+                norm(n + ".norm")
+                w[n + ".qkv"] = pk.pack([d + ".q", d + ".k", d + ".v"], n_out=2 * Lr.ch)
+                w[n + ".proj_out"] = pk.pack(d + ".proj_out")
+            elif Lr.kind == "upconv":
+                w[n] = pk.pack(d)
+            elif Lr.kind == "norm_out":
+                norm(n)
+        self.w, self.v = w, v
+
+
+class VAEDecodePlan(Emitter):
+    """decode_first_stage (ddpm.py:771-829 plain branch): z / scale_factor ->
+    post_quant_conv -> Decoder (model.py:535-568) -> fp32 NCHW image."""
+
+    def __init__(self, ctx, packed: PackedVAEDecoder, B, h, w, scale_factor):
+        super().__init__(ctx)
+        self.pk, self.arch = packed, packed.arch
+        a = self.arch
+        self.B, self.h, self.w = B, h, w
+        f = a.factor
+        self.z = self.alloc(B, a.embed_dim, h, w, dtype=torch.float32)
+        self.img = self.alloc(B, a.out_ch, h * f, w * f, dtype=torch.float32)
+        self.gn_ws = self.alloc(max(64, ctx.groupnorm_ws_bytes(B, h * f * w * f) // 4), dtype=torch.float32)
+        self.prog = Program(ctx)
+        P, W_, V_ = self.prog, packed.w, packed.v
+        zin = Act(self.alloc(B * h * w, _rup(a.embed_dim, 32), zero=True), B, h, w, a.embed_dim)
+        lib, hh, chk, z = self.lib, self.h, self._chk, self.z
+        inv = 1.0 / float(scale_factor)
+        P.add(lambda s: chk(lib.upk_nchw_f32_to_nhwc_f16(hh, z.data_ptr(), B, a.embed_dim, h * w, zin.t.data_ptr(),
+                                                         zin.ld, 0, 0, inv, s)))
+        x = self.conv(P, zin, W_["post_quant_conv"],
+                      out=Act(self.alloc(B * h * w, _rup(a.z_channels, 32), zero=True), B, h, w, a.z_channels))
+        for Lr in a.decoder:
+            n = Lr.name
+            if Lr.kind == "conv":
+                x = self.conv(P, x, W_[n])
+            elif Lr.kind == "resnet":
+                hN = self.groupnorm(P, x, *V_[n + ".norm1"], 1e-6, True, self.gn_ws)
+                h1 = self.conv(P, hN, W_[n + ".conv1"])
+                hN = self.groupnorm(P, h1, *V_[n + ".norm2"], 1e-6, True, self.gn_ws)
+                sk = self.conv(P, x, W_[n + ".nin_shortcut"]) if Lr.cin != Lr.cout else x
+                x = self.conv(P, hN, W_[n + ".conv2"], residual=sk)
+            elif Lr.kind == "attn":
+                c, HW = Lr.ch, x.H * x.W
+                xn = self.groupnorm(P, x, *V_[n + ".norm"], 1e-6, False, self.gn_ws)
+                qk = Act(self.alloc(x.M, 2 * c), x.B, x.H, x.W, 2 * c)
+                vt_ld = _rup(HW, 32)
+                vt = self.alloc(x.B, 1, c, vt_ld, zero=True)
+                self.conv(P, xn, W_[n + ".qkv"], out=qk,
+                          vt=dict(t=vt, heads=1, dhead=c, ld=vt_ld, tokens=HW, **{"from": 2 * c}))
+                ao = Act(self.alloc(x.M, c), x.B, x.H, x.W, c)
+                self.attention(P, qk.t, 2 * c, HW * 2 * c, qk.t[:, c:], 2 * c, HW * 2 * c, vt, vt_ld, ao.t, c, HW * c,
+                               x.B, 1, HW, HW, c, int(c) ** -0.5)
+                x = self.conv(P, ao, W_[n + ".proj_out"], residual=x)
+            elif Lr.kind == "upconv":
+                x = self.conv(P, x, W_[n], flags=L.F_UPSAMPLE2X)
+            elif Lr.kind == "norm_out":
+                x = self.groupnorm(P, x, *V_[n], 1e-6, True, self.gn_ws)
+            elif Lr.kind == "conv_out":
+                self.conv(P, x, W_[n], nchw_out=self.img)
+        self.graph = None
+
+    def run(self, z):
+        z = z.to(self.dev, torch.float32).contiguous()
+        assert tuple(z.shape) == tuple(self.z.shape), (z.shape, self.z.shape)
+        self.z.copy_(z)
+        self.prog.run()
+        return self.img
+
+
+# ====================================================================== sampler step graph
+class SamplerState:
+    """Device state of one DDIM run on a sampler-mode UNetPlan: latent x (fp32 NCHW),
+    pred_x0, the per-step coefficient / noise tables and the captured step graph
+    (UNet body -> upk_ddim_step_f32 -> upk_advance_step)."""
+
+    def __init__(self, plan: UNetPlan, channels):
+        assert plan.mode == "sampler"
+        self.plan = plan
+        B, H, W, R = plan.B, plan.H, plan.W, plan.rows
+        self.C = channels
+        self.x = plan.alloc(B, channels, H, W, dtype=torch.float32)
+        self.pred_x0 = plan.alloc(B, channels, H, W, dtype=torch.float32)
+        self.coefs = plan.alloc(R, 4, dtype=torch.float32)
+        self.noise = None
+        self.graphs = {}
+
+    def ensure_noise(self):
+        if self.noise is None:
+            p = self.plan
+            self.noise = p.alloc(p.rows, p.B * self.C * p.H * p.W, dtype=torch.float32)
+        return self.noise
+
+    def _emit_tail(self, stream, with_noise):
+        p = self.plan
+        p.ctx._chk(p.lib.upk_ddim_step_f32(p.h, self.x.data_ptr(), p.eps.data_ptr(), self.coefs.data_ptr(),
+                                           self.noise.data_ptr() if with_noise else None, p.step.data_ptr(),
+                                           self.pred_x0.data_ptr(), p.xin.t.data_ptr(), p.xin.ld, p.B, self.C,
+                                           p.H * p.W, stream))
+        p.ctx._chk(p.lib.upk_advance_step(p.h, p.step.data_ptr(), stream))
+
+    def step_eager(self, with_noise):
+        s = self.plan.ctx._s()
+        self.plan.body.run(s)
+        self._emit_tail(s, with_noise)
+
+    def graph(self, with_noise):
+        """One DDIM step captured as a HIP graph (static shapes, device-side step index)."""
+        g = self.graphs.get(with_noise)
+        if g is None:
+            p = self.plan
+            if with_noise:
+                self.ensure_noise()
+            side = torch.cuda.Stream(device=p.dev)
+            side.wait_stream(torch.cuda.current_stream(p.dev))
+            sp = side.cuda_stream
+            p.ctx._chk(p.lib.upk_graph_begin(p.h, sp))
+            try:
+                p.body.run(sp)
+                self._emit_tail(sp, with_noise)
+            finally:
+                gh = C.c_void_p()
+                rc = p.lib.upk_graph_end(p.h, sp, C.byref(gh))
+            p.ctx._chk(rc)
+            torch.cuda.current_stream(p.dev).wait_stream(side)
+            g = self.graphs[with_noise] = gh
+        return g
+
+    def launch(self, with_noise):
+        p = self.plan
+        p.ctx._chk(p.lib.upk_graph_launch(p.h, self.graph(with_noise), p.ctx._s()))
