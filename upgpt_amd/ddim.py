@@ -59,7 +59,7 @@ class DDIMSampler(object):
         self.ddim_sigmas = sigmas
         self.ddim_alphas = alphas
         self.ddim_alphas_prev = alphas_prev
-        self.ddim_sqrt_one_minus_alphas = np.sqrt(1. - alphas)
+        self.ddim_sqrt_one_minus_alphas = torch.sqrt(1. - alphas)  # fp32, like np.sqrt on the fp32 tensor (ddim.py:49)
         self.register_buffer("ddim_sigmas_for_original_num_steps", ddim_eta * torch.sqrt(
             (1 - self.alphas_cumprod_prev) / (1 - self.alphas_cumprod) *
             (1 - self.alphas_cumprod / self.alphas_cumprod_prev)))
