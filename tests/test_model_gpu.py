@@ -154,7 +154,7 @@ def test_general_path_equals_fused_path():
     assert mse(x, z_fast.cpu()) < 1e-6
     # classifier-free guidance with dict conditioning (superset of the reference)
     uc = {"c_crossattn": torch.zeros_like(cond["c_crossattn"]), "c_concat": cond["c_concat"]}
-    zg, _ = s.sample(3, 2, (4, 32, 24), cond, eta=0.0, x_T=inp["x_T"].cuda(), verbose=False,
+    zg, _ = s.sample(4, 2, (4, 32, 24), cond, eta=0.0, x_T=inp["x_T"].cuda(), verbose=False,
                      unconditional_guidance_scale=3.0, unconditional_conditioning=uc)
     assert torch.isfinite(zg).all() and zg.shape == (2, 4, 32, 24)
 
@@ -193,9 +193,9 @@ def test_text_only_and_full_cond_share_shapes():
     b = synth.synth_inputs(2, (32, 24), 4, 87, 768, seed=0, text_only=False)
     assert a["c_crossattn"].shape == b["c_crossattn"].shape == (2, 87, 768)
     s = DDIMSampler(model)
-    za, _ = s.sample(3, 2, (4, 32, 24), {"c_crossattn": a["c_crossattn"].cuda(), "c_concat": [a["c_concat"].cuda()]},
+    za, _ = s.sample(4, 2, (4, 32, 24), {"c_crossattn": a["c_crossattn"].cuda(), "c_concat": [a["c_concat"].cuda()]},
                      x_T=a["x_T"].cuda(), verbose=False)
-    zb, _ = s.sample(3, 2, (4, 32, 24), {"c_crossattn": b["c_crossattn"].cuda(), "c_concat": [b["c_concat"].cuda()]},
+    zb, _ = s.sample(4, 2, (4, 32, 24), {"c_crossattn": b["c_crossattn"].cuda(), "c_concat": [b["c_concat"].cuda()]},
                      x_T=b["x_T"].cuda(), verbose=False)
     assert not torch.equal(za, zb)
 

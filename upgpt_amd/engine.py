@@ -146,7 +146,7 @@ class Emitter:
     def __init__(self, ctx):
         self.ctx = ctx
         self.lib = ctx.lib
-        self.h = ctx.h
+        self.hctx = ctx.h
         self.dev = ctx.device
         self.bufs = []
 
@@ -218,7 +218,7 @@ class Emitter:
             d.vt_from, d.vt_heads, d.vt_dhead = vt["from"], vt["heads"], vt["dhead"]
             d.vt_ld, d.vt_tokens = vt["ld"], vt["tokens"]
         d.flags = flags
-        fn, h, ref = self.lib.upk_conv2d_nhwc_f16, self.h, C.byref(d)
+        fn, h, ref = self.lib.upk_conv2d_nhwc_f16, self.hctx, C.byref(d)
         chk = self._chk
         P.add(lambda s: chk(fn(h, ref, s)), d, pw, x1, x2, residual, rowvec, out, nchw_out, out_f32, vt)
         P.igemm_flops += 2 * M * pw.n_real * pw.k_real
@@ -227,7 +227,7 @@ class Emitter:
     def groupnorm(self, P, x1, gamma, beta, eps, silu, ws, x2=None):
         Cc = x1.C + (x2.C if x2 is not None else 0)
         y = Act(self.alloc(x1.M, Cc), x1.B, x1.H, x1.W, Cc)
-        fn, h, chk = self.lib.upk_groupnorm_nhwc_f16, self.h, self._chk
+        fn, h, chk = self.lib.upk_groupnorm_nhwc_f16, self.hctx, self._chk
         a = (x1.t.data_ptr(), x1.C, x1.ld, x2.t.data_ptr() if x2 is not None else None, x2.C if x2 is not None else 0,
              x2.ld if x2 is not None else 0, x1.B, x1.H * x1.W, 32, gamma.data_ptr(), beta.data_ptr(), float(eps),
              int(bool(silu)), y.t.data_ptr(), y.ld, ws.data_ptr())
@@ -237,13 +237,13 @@ class Emitter:
 
     def layernorm(self, P, x, gamma, beta, eps=1e-5):
         y = Act(self.alloc(x.M, x.C), x.B, x.H, x.W, x.C)
-        fn, h, chk = self.lib.upk_layernorm_f16, self.h, self._chk
+        fn, h, chk = self.lib.upk_layernorm_f16, self.hctx, self._chk
         a = (x.t.data_ptr(), x.ld, x.M, x.C, gamma.data_ptr(), beta.data_ptr(), float(eps), y.t.data_ptr(), y.ld)
         P.add(lambda s: chk(fn(h, *a, s)), x, gamma, beta, y)
         return y
 
     def attention(self, P, q, ldq, qbs, k, ldk, kbs, vt, vt_ld, out, ldo, obs, B, heads, nq, nkv, dp, scale):
-        fn, h, chk = self.lib.upk_attention_f16, self.h, self._chk
+        fn, h, chk = self.lib.upk_attention_f16, self.hctx, self._chk
         a = (q.data_ptr(), ldq, qbs, k.data_ptr(), ldk, kbs, vt.data_ptr(), vt_ld, out.data_ptr(), ldo, obs, B, heads,
              nq, nkv, dp, float(scale))
         P.add(lambda s: chk(fn(h, *a, s)), q, k, vt, out)
@@ -345,7 +345,7 @@ class UNetPlan(Emitter):
     def _emit_prep(self):
         P, a, w = self.prep, self.arch, self.pk.w
         mc, te, R = a.model_channels, a.time_embed_dim, self.rows
-        lib, h, chk = self.lib, self.h, self._chk
+        lib, h, chk = self.lib, self.hctx, self._chk
         c32, c16 = self.ctx32, self.ctx16
         P.add(lambda s: chk(lib.upk_f32_to_f16(h, c32.data_ptr(), c32.shape[0], c32.shape[1], c16.t.data_ptr(),
                                                c16.ld, s)))
@@ -531,7 +531,7 @@ class VAEDecodePlan(Emitter):
         self.prog = Program(ctx)
         P, W_, V_ = self.prog, packed.w, packed.v
         zin = Act(self.alloc(B * h * w, _rup(a.embed_dim, 32), zero=True), B, h, w, a.embed_dim)
-        lib, hh, chk, z = self.lib, self.h, self._chk, self.z
+        lib, hh, chk, z = self.lib, self.hctx, self._chk, self.z
         inv = 1.0 / float(scale_factor)
         P.add(lambda s: chk(lib.upk_nchw_f32_to_nhwc_f16(hh, z.data_ptr(), B, a.embed_dim, h * w, zin.t.data_ptr(),
                                                          zin.ld, 0, 0, inv, s)))
@@ -600,11 +600,11 @@ class SamplerState:
 
     def _emit_tail(self, stream, with_noise):
         p = self.plan
-        p.ctx._chk(p.lib.upk_ddim_step_f32(p.h, self.x.data_ptr(), p.eps.data_ptr(), self.coefs.data_ptr(),
+        p.ctx._chk(p.lib.upk_ddim_step_f32(p.hctx, self.x.data_ptr(), p.eps.data_ptr(), self.coefs.data_ptr(),
                                            self.noise.data_ptr() if with_noise else None, p.step.data_ptr(),
                                            self.pred_x0.data_ptr(), p.xin.t.data_ptr(), p.xin.ld, p.B, self.C,
                                            p.H * p.W, stream))
-        p.ctx._chk(p.lib.upk_advance_step(p.h, p.step.data_ptr(), stream))
+        p.ctx._chk(p.lib.upk_advance_step(p.hctx, p.step.data_ptr(), stream))
 
     def step_eager(self, with_noise):
         s = self.plan.ctx._s()
@@ -621,13 +621,13 @@ class SamplerState:
             side = torch.cuda.Stream(device=p.dev)
             side.wait_stream(torch.cuda.current_stream(p.dev))
             sp = side.cuda_stream
-            p.ctx._chk(p.lib.upk_graph_begin(p.h, sp))
+            p.ctx._chk(p.lib.upk_graph_begin(p.hctx, sp))
             try:
                 p.body.run(sp)
                 self._emit_tail(sp, with_noise)
             finally:
                 gh = C.c_void_p()
-                rc = p.lib.upk_graph_end(p.h, sp, C.byref(gh))
+                rc = p.lib.upk_graph_end(p.hctx, sp, C.byref(gh))
             p.ctx._chk(rc)
             torch.cuda.current_stream(p.dev).wait_stream(side)
             g = self.graphs[with_noise] = gh
@@ -635,4 +635,4 @@ class SamplerState:
 
     def launch(self, with_noise):
         p = self.plan
-        p.ctx._chk(p.lib.upk_graph_launch(p.h, self.graph(with_noise), p.ctx._s()))
+        p.ctx._chk(p.lib.upk_graph_launch(p.hctx, self.graph(with_noise), p.ctx._s()))
