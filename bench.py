@@ -1,0 +1,228 @@
+#!/usr/bin/env python
+"""bench.py — the reference's headline metric on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one batch per GPU: x_T -> 50 x (UNetModel forward
++ DDIM update) -> VAE decode -> images on the device (+ one RCCL all-gather of the images
+when N > 1).  Workload = BASELINE.json configs[1]: bs=8/GPU, 256x256 px (latent 4x32x32),
+50-step DDIM, eta=0, 1 UNet forward per step (no CFG), text-only conditioning [8,87,768],
+fp16 kernels with fp32 accumulation, synthetic inputs and recipe weights already resident
+in HBM.  value = images/s over all ranks.  The config-true 256x192 (latent 32x24) rate is
+reported next to it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F16_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+class Workload:
+    """bbox.yaml model + synthetic conditioning on one GPU; run() = one bench step."""
+
+    def __init__(self, model, batch, hw, ddim_steps, seed, text_only=True):
+        from upgpt_amd import synth
+        from upgpt_amd.ddim import DDIMSampler
+        self.model, self.B, self.hw, self.S = model, batch, hw, ddim_steps
+        inp = synth.synth_inputs(batch, hw, 4, 87, 768, seed=seed, text_only=text_only)
+        self.x_T = inp["x_T"].cuda()
+        self.cond = {"c_crossattn": inp["c_crossattn"].cuda(), "c_concat": [inp["c_concat"].cuda()]}
+        self.sampler = DDIMSampler(model)
+
+    def run(self):
+        with self.model.ema_scope():
+            z, _ = self.sampler.sample(self.S, self.B, (4,) + tuple(self.hw), self.cond, eta=0.0, x_T=self.x_T,
+                                       verbose=False, log_every_t=10 ** 6)
+        return self.model.decode_first_stage(z)
+
+
+def quiet(fn, *a, **k):
+    """The sampler prints like the reference does; keep stdout clean for the JSON line."""
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def timed(fn, n, dev):
+    from upgpt_amd import dist as D
+    D.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        out = fn()
+    torch.cuda.synchronize(dev)
+    D.barrier()
+    return time.perf_counter() - t0, out
+
+
+def kernel_class_profile(model, wl, reps=3):
+    """Per-kernel-class durations measured live with HIP events on the launch stream
+    (upk_prof_*), over `reps` eager UNet forwards of the bench workload."""
+    from upgpt_amd._lib import get_context
+    ctx = get_context(0)
+    unet = model.model.diffusion_model
+    B, (H, W) = wl.B, wl.hw
+    with model.ema_scope():
+        plan = unet.plan(B, H, W, 87, wl.S, "sampler")
+        plan.step.zero_()
+        plan.body.run()  # warm
+        torch.cuda.synchronize()
+        ctx.prof_enable(True)
+        for _ in range(reps):
+            plan.step.zero_()
+            plan.body.run()
+        torch.cuda.synchronize()
+        res = ctx.prof_collect()
+        ctx.prof_enable(False)
+    out = {k: {"ms_per_fwd": v[0] / reps, "launches_per_fwd": v[1] / reps} for k, v in res.items()}
+    return out, plan.body.igemm_flops, plan.body.attn_flops, plan.body.n_launch
+
+
+def unet_forward_ms(model, wl, reps=20):
+    """Graph-replayed UNet forward + DDIM update (one sampler step), ms."""
+    unet = model.model.diffusion_model
+    with model.ema_scope():
+        plan = unet.plan(wl.B, wl.hw[0], wl.hw[1], 87, wl.S, "sampler")
+        st = plan._sampler_state
+        plan.step.zero_()
+        st.launch(False)
+        torch.cuda.synchronize()
+        plan.step.zero_()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            st.launch(False)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        plan.step.zero_()
+    return dt * 1e3
+
+
+def cpu_baseline(hw, ddim_steps, batch):
+    """The CPU oracle (port of the reference algorithm, validated against the real reference
+    in tests/test_oracle_golden.py) timed on this host: a bounded sample (UNet forwards at the
+    bench batch + one B=1 decode), extrapolated to the metric's unit."""
+    from oracle import unet as o_unet, vae as o_vae
+    from upgpt_amd import arch, synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    shapes = {"model.diffusion_model." + k: v for k, v in arch.UNetArch(**synth.BBOX_UNET).param_shapes().items()}
+    shapes.update({"first_stage_model." + k: v for k, v in arch.VAEArch(synth.BBOX_DDCONFIG, 4).param_shapes().items()})
+    sd = synth.synth_state_dict(shapes)
+    inp = synth.synth_inputs(batch, hw, 4, 87, 768, seed=0, text_only=True)
+    x = torch.cat([inp["x_T"], inp["c_concat"]], 1)
+    t = torch.full((batch,), 981, dtype=torch.long)
+    o_unet.unet_forward(sd, synth.BBOX_UNET, x[:1], t[:1], inp["c_crossattn"][:1])  # warm-up
+    n_fwd, t0 = 0, time.perf_counter()
+    while n_fwd < 3 or (time.perf_counter() - t0 < 12 and n_fwd < 8):
+        o_unet.unet_forward(sd, synth.BBOX_UNET, x, t, inp["c_crossattn"])
+        n_fwd += 1
+    t_fwd = (time.perf_counter() - t0) / n_fwd
+    t0 = time.perf_counter()
+    o_vae.decode_first_stage(sd, synth.BBOX_DDCONFIG, inp["x_T"][:1])
+    t_dec = time.perf_counter() - t0
+    total = ddim_steps * t_fwd + batch * t_dec
+    return {"value": batch / total, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d UNet forwards at B=%d latent %dx%d (%.2f s each) + one B=1 VAE decode (%.2f s), fp32 "
+                      "torch-CPU oracle, extrapolated to %d steps + %d decodes" % (n_fwd, batch, hw[0], hw[1], t_fwd,
+                                                                                 t_dec, ddim_steps, batch),
+            "unet_fwd_s": t_fwd, "decode_b1_s": t_dec}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--latent", default="32x32", help="HxW of the latent (32x32 = 256x256 px)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    args = ap.parse_args()
+
+    from upgpt_amd import dist as D
+    rank, local_rank, world = D.init_from_env("nccl" if args.gpus > 1 else None)
+    assert world == args.gpus, "WORLD_SIZE %d != --gpus %d (launch with torch.distributed.run)" % (world, args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import upgpt_amd
+    from upgpt_amd import arch, synth
+    hw = tuple(int(v) for v in args.latent.split("x"))
+    t0 = time.time()
+    model = quiet(upgpt_amd.build_model, "bbox")
+    synth.fill_module_(model)
+    model = model.cuda()
+    log("[bench] rank %d model ready in %.1fs" % (rank, time.time() - t0))
+    wl = Workload(model, args.batch, hw, args.ddim_steps, seed=rank)
+
+    def step():
+        img = quiet(wl.run)
+        return D.all_gather_images(img)
+
+    for _ in range(args.warmup):
+        step()
+    dt, out = timed(step, args.steps, dev)
+    dt = D.max_over_ranks(dt, dev)
+    assert out.shape[0] == args.batch * world and torch.isfinite(out).all()
+    images = args.batch * world * args.steps
+    result = {
+        "metric": "256x256 images/sec, 50-step DDIM, bs=8/GPU; UNet MFMA util %",
+        "value": images / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: bs=%d/GPU, %dx%d px (latent 4x%dx%d), %d-step DDIM eta=0, "
+                               "text-only cond [B,87,768], UNet(bbox.yaml) + VAE decode, EMA weights, no CFG" % (
+                                   args.batch, hw[0] * 8, hw[1] * 8, hw[0], hw[1], args.ddim_steps),
+                   "batch_per_gpu": args.batch, "ddim_steps": args.ddim_steps, "latent": list(hw),
+                   "parallelism": "replica-dp%d, one all-gather of images per batch" % world},
+    }
+    if rank == 0:
+        a = arch.UNetArch(**synth.BBOX_UNET)
+        flops_fwd = a.flops(args.batch, hw[0], hw[1], 87)
+        fwd_ms = unet_forward_ms(model, wl)
+        prof, ig_flops, at_flops, n_launch = kernel_class_profile(model, wl)
+        ig_ms = prof["igemm"]["ms_per_fwd"]
+        achieved = ig_flops / (ig_ms * 1e-3) / 1e12
+        result["roofline"] = {
+            "bound": "mfma", "kernel": "igemm_kernel<*> (implicit-GEMM conv/linear, all tile configs)",
+            "achieved": achieved, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F16_TFLOPS,
+            "traffic": None,
+            "algorithmic_flops_per_fwd": ig_flops, "avg_launch_us": ig_ms * 1e3 / max(1.0, prof["igemm"]["launches_per_fwd"]),
+            "launches_per_fwd": prof["igemm"]["launches_per_fwd"],
+        }
+        result["unet"] = {"fwd_ms_graph": fwd_ms, "algorithmic_gflop_per_fwd": flops_fwd / 1e9,
+                          "mfma_util": flops_fwd / (fwd_ms * 1e-3) / (PEAK_MFMA_F16_TFLOPS * 1e12),
+                          "kernel_launches_per_fwd": n_launch, "class_ms_per_fwd": {k: v["ms_per_fwd"] for k, v in prof.items()}}
+        tdec, _ = timed(lambda: model.decode_first_stage(wl.x_T), 3, dev) if world == 1 else (None, None)
+        if tdec is not None:
+            result["vae_decode_ms"] = tdec / 3 * 1e3
+        if not args.no_secondary and world == 1 and hw != (32, 24):
+            wl2 = Workload(model, args.batch, (32, 24), args.ddim_steps, seed=rank)
+            quiet(wl2.run)
+            dt2, _ = timed(lambda: quiet(wl2.run), max(2, args.steps // 2), dev)
+            result["config_true_256x192"] = {"value": args.batch * max(2, args.steps // 2) / dt2, "unit": "images/s",
+                                             "unet_fwd_ms_graph": unet_forward_ms(model, wl2),
+                                             "algorithmic_gflop_per_fwd": a.flops(args.batch, 32, 24, 87) / 1e9}
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(hw, args.ddim_steps, args.batch)
+        print(json.dumps(result), flush=True)
+    D.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -35,12 +35,12 @@ extern "C" int upk_create(upk_ctx** out, int device) {
 extern "C" int upk_destroy(upk_ctx* ctx) {
   if (!ctx) return UPK_EINVAL;
   for (auto& r : ctx->recs) {
-    hipEventDestroy(r.e0);
-    hipEventDestroy(r.e1);
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
   }
   for (auto& r : ctx->free_recs) {
-    hipEventDestroy(r.e0);
-    hipEventDestroy(r.e1);
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
   }
   delete ctx;
   return UPK_OK;
@@ -264,7 +264,7 @@ extern "C" int upk_graph_end(upk_ctx* ctx, upk_stream stream, upk_graph** out) {
   hipGraphExec_t e = nullptr;
   hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
   if (err != hipSuccess) {
-    hipGraphDestroy(g);
+    (void)hipGraphDestroy(g);
     return upk_fail(ctx, UPK_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(err));
   }
   upk_graph* h = new upk_graph();
@@ -282,8 +282,8 @@ extern "C" int upk_graph_launch(upk_ctx* ctx, upk_graph* g, upk_stream stream) {
 
 extern "C" int upk_graph_destroy(upk_ctx* ctx, upk_graph* g) {
   if (!g) return UPK_EINVAL;
-  hipGraphExecDestroy(g->exec);
-  hipGraphDestroy(g->graph);
+  (void)hipGraphExecDestroy(g->exec);
+  (void)hipGraphDestroy(g->graph);
   delete g;
   return UPK_OK;
 }
