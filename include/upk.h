@@ -118,6 +118,9 @@ typedef struct upk_conv_desc {
   void* vt;
   int32_t vt_from, vt_heads, vt_dhead, vt_ld, vt_tokens;
   int32_t flags;
+  /* tile configuration = tune_cfg - 1 and split-K factor chosen by upk_conv_autotune
+   * (0 = let the built-in cost model decide). */
+  int32_t tune_cfg, tune_splitk;
 } upk_conv_desc;
 
 /* Replaces F.conv2d (3x3 s1/s2 p1, 1x1) / F.linear call sites:
@@ -132,6 +135,13 @@ int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream)
 int upk_gemm_f16(upk_ctx* ctx, const void* a, int lda, int m, int k, const void* w_packed,
                  int n_out, int n_pad, const float* bias, const void* residual, int ld_res,
                  void* y, int ldy, int flags, upk_stream stream);
+
+/* Times every (tile configuration, split-K) candidate for this descriptor with HIP events on
+ * `stream` (synchronises; call at plan-build time, never inside a captured region) and
+ * returns the fastest pair (cfg is 0-based), its time, and the time of the cost model's
+ * default choice.  The outputs of the descriptor are overwritten `reps` times per candidate. */
+int upk_conv_autotune(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream, int reps, int* best_cfg,
+                      int* best_splitk, float* best_us, float* default_us);
 
 /* Forces a tile configuration / split-K factor for the next launches (tuning
  * and tests). cfg < 0 and splitk <= 0 restore the heuristic. */

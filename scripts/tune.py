@@ -1,0 +1,53 @@
+"""Autotunes every conv/GEMM launch of the bench workloads on the GPU and writes the tuning
+cache (copy gpurun_out/tuned_gfx950.json to upgpt_amd/tuned_gfx950.json and commit).
+
+    UPGPT_AUTOTUNE=1 python scripts/tune.py [out.json]
+"""
+import contextlib
+import io
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["UPGPT_AUTOTUNE"] = "1"
+import upgpt_amd  # noqa: E402
+from upgpt_amd import synth  # noqa: E402
+from upgpt_amd.engine import TUNE_CACHE  # noqa: E402
+
+out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/tuned_gfx950.json"
+kinds = sys.argv[2].split(",") if len(sys.argv) > 2 else ["bbox"]
+
+
+def summarize(name, emitter):
+    best = dflt = 0.0
+    for d, key in emitter.convs:
+        e = TUNE_CACHE.get(key)
+        best += e[2]
+        dflt += e[3]
+    print("%-40s %4d convs: cost-model %.0f us -> tuned %.0f us" % (name, len(emitter.convs), dflt, best), flush=True)
+
+
+for kind in kinds:
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = upgpt_amd.build_model(kind)
+    synth.fill_module_(model)
+    model = model.cuda()
+    unet = model.model.diffusion_model
+    C = model.channels
+    ntok = 86 if kind == "upscale" else 87
+    shapes = [(8, 32, 32, 50), (8, 32, 24, 50)] if kind == "bbox" else [(4, 64, 64, 50)]
+    for (B, H, W, S) in shapes:
+        t0 = time.time()
+        pl = unet.plan(B, H, W, ntok, S, "sampler")
+        summarize("%s unet sampler B=%d %dx%d (%.0fs)" % (kind, B, H, W, time.time() - t0), pl)
+        TUNE_CACHE.save(out)
+        t0 = time.time()
+        vp = model.first_stage_model._decode_plan(B, H, W, 0.18215)
+        summarize("%s vae decode B=%d %dx%d (%.0fs)" % (kind, B, H, W, time.time() - t0), vp)
+        TUNE_CACHE.save(out)
+    del model
+    torch.cuda.empty_cache()
+print("entries:", len(TUNE_CACHE.d), "->", out)

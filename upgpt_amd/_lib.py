@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libupk.so")
 SYMBOLS = [
     "upk_version", "upk_create", "upk_destroy", "upk_last_error", "upk_set_workspace", "upk_num_cus",
     "upk_pack_weight_f16", "upk_packed_weight_bytes", "upk_conv2d_nhwc_f16", "upk_gemm_f16",
-    "upk_conv_override", "upk_conv_num_configs", "upk_conv_config_name", "upk_attention_f16",
+    "upk_conv_autotune", "upk_conv_override", "upk_conv_num_configs", "upk_conv_config_name", "upk_attention_f16",
     "upk_groupnorm_nhwc_f16", "upk_groupnorm_ws_bytes", "upk_layernorm_f16", "upk_timestep_embed_f16",
     "upk_nchw_f32_to_nhwc_f16", "upk_nhwc_f16_to_nchw_f32", "upk_f32_to_f16", "upk_ddim_step_f32",
     "upk_advance_step", "upk_graph_begin", "upk_graph_end", "upk_graph_launch", "upk_graph_destroy",
@@ -50,6 +50,7 @@ class ConvDesc(C.Structure):
         ("step", C.c_void_p), ("y", C.c_void_p), ("ldy", C.c_int32),
         ("vt", C.c_void_p), ("vt_from", C.c_int32), ("vt_heads", C.c_int32), ("vt_dhead", C.c_int32),
         ("vt_ld", C.c_int32), ("vt_tokens", C.c_int32), ("flags", C.c_int32),
+        ("tune_cfg", C.c_int32), ("tune_splitk", C.c_int32),
     ]
 
 
@@ -81,6 +82,8 @@ def load_library(path=None):
             "upk_packed_weight_bytes": (C.c_size_t, [i32, i32, i32, i32]),
             "upk_conv2d_nhwc_f16": (C.c_int, [vp, C.POINTER(ConvDesc), vp]),
             "upk_gemm_f16": (C.c_int, [vp, vp, i32, i32, i32, vp, i32, i32, vp, vp, i32, vp, i32, i32, vp]),
+            "upk_conv_autotune": (C.c_int, [vp, C.POINTER(ConvDesc), vp, i32, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                            C.POINTER(C.c_float), C.POINTER(C.c_float)]),
             "upk_conv_override": (C.c_int, [vp, i32, i32]),
             "upk_conv_num_configs": (C.c_int, []),
             "upk_conv_config_name": (C.c_char_p, [i32]),
@@ -168,6 +171,13 @@ class Context:
     def gemm(self, a, lda, m, k, w, n_out, n_pad, bias, res, ld_res, y, ldy, flags=0):
         self._chk(self.lib.upk_gemm_f16(self.h, _ptr(a), lda, m, k, _ptr(w), n_out, n_pad, _ptr(bias), _ptr(res),
                                         ld_res, _ptr(y), ldy, flags, self._s()))
+
+    def conv_autotune(self, desc, reps=5):
+        """-> (cfg, splitk, best_us, default_us); synchronises the stream."""
+        cfg, sk, bu, du = C.c_int(), C.c_int(), C.c_float(), C.c_float()
+        self._chk(self.lib.upk_conv_autotune(self.h, C.byref(desc), self._s(), reps, C.byref(cfg), C.byref(sk),
+                                             C.byref(bu), C.byref(du)))
+        return cfg.value, sk.value, bu.value, du.value
 
     def conv_override(self, cfg=-1, splitk=0):
         self._chk(self.lib.upk_conv_override(self.h, cfg, splitk))

@@ -490,10 +490,12 @@ extern "C" int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_str
   double best_t = 1e30;
   const int sk_cands[] = {1, 2, 3, 4, 6, 8, 9, 12, 16, 18};
   const size_t slab = (size_t)a.M * a.npad * sizeof(float);
+  const int want_cfg = ctx->cfg_override >= 0 ? ctx->cfg_override : (d->tune_cfg > 0 ? d->tune_cfg - 1 : -1);
+  const int want_sk = ctx->splitk_override > 0 ? ctx->splitk_override : (d->tune_splitk > 0 ? d->tune_splitk : 0);
   for (int c = 0; c < kNumCfgs; ++c) {
-    if (ctx->cfg_override >= 0 && c != ctx->cfg_override) continue;
+    if (want_cfg >= 0 && c != want_cfg) continue;
     for (int sk : sk_cands) {
-      if (ctx->splitk_override > 0 && sk != ctx->splitk_override) continue;
+      if (want_sk > 0 && sk != want_sk) continue;
       if (sk > 1 && (slab * sk > ctx->ws_bytes || a.nchunks / sk < 4)) continue;
       const double t = estimate(kCfgs[c], a.M, a.npad, a.nchunks, sk, ctx->num_cus, geglu);
       if (t < best_t) {
@@ -504,9 +506,9 @@ extern "C" int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_str
     }
   }
   if (best < 0) {
-    if (ctx->splitk_override > 1 && slab * ctx->splitk_override > ctx->ws_bytes)
-      return upk_fail(ctx, UPK_EWORKSPACE, "conv: split-K %d needs %zu workspace bytes, have %zu",
-                      ctx->splitk_override, slab * ctx->splitk_override, ctx->ws_bytes);
+    if (want_sk > 1 && slab * want_sk > ctx->ws_bytes)
+      return upk_fail(ctx, UPK_EWORKSPACE, "conv: split-K %d needs %zu workspace bytes, have %zu", want_sk,
+                      slab * want_sk, ctx->ws_bytes);
     return upk_fail(ctx, UPK_ESHAPE, "conv: no kernel configuration fits (geglu=%d)", (int)geglu);
   }
   const CfgInfo& c = kCfgs[best];
@@ -528,6 +530,63 @@ extern "C" int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_str
     rc = upk_check_launch(ctx, "igemm_reduce");
   }
   return rc;
+}
+
+extern "C" int upk_conv_autotune(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, int reps, int* best_cfg,
+                                 int* best_splitk, float* best_us, float* default_us) {
+  if (!ctx || !d || !best_cfg || !best_splitk) return UPK_EINVAL;
+  if (ctx->prof_on) return upk_fail(ctx, UPK_EINVAL, "autotune with profiling enabled");
+  hipStream_t stream = (hipStream_t)stream_;
+  if (reps < 1) reps = 1;
+  hipEvent_t e0, e1;
+  UPK_HIP(ctx, hipEventCreate(&e0));
+  UPK_HIP(ctx, hipEventCreate(&e1));
+  const int save_cfg = ctx->cfg_override, save_sk = ctx->splitk_override;
+  upk_conv_desc dd = *d;
+  dd.tune_cfg = 0;
+  dd.tune_splitk = 0;
+  auto time_one = [&](int cfg, int sk, float* us) -> int {
+    ctx->cfg_override = cfg;
+    ctx->splitk_override = sk;
+    int rc = upk_conv2d_nhwc_f16(ctx, &dd, stream);  // warm-up + feasibility
+    if (rc) return rc;
+    if (hipEventRecord(e0, stream) != hipSuccess) return UPK_EHIP;
+    for (int r = 0; r < reps; ++r) rc |= upk_conv2d_nhwc_f16(ctx, &dd, stream);
+    if (hipEventRecord(e1, stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return UPK_EHIP;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return UPK_EHIP;
+    *us = ms * 1000.f / reps;
+    return rc;
+  };
+  float dflt = 0.f;
+  int rc = time_one(-1, 0, &dflt);
+  float best = 1e30f;
+  int bc = -1, bs = 1;
+  if (rc == UPK_OK) {
+    const int sks[] = {1, 2, 3, 4, 6, 8, 9, 12, 16, 18};
+    for (int c = 0; c < kNumCfgs; ++c)
+      for (int sk : sks) {
+        float us = 0.f;
+        if (time_one(c, sk, &us) != UPK_OK) continue;  // infeasible candidate
+        if (us < best) {
+          best = us;
+          bc = c;
+          bs = sk;
+        }
+      }
+    ctx->err[0] = 0;
+  }
+  ctx->cfg_override = save_cfg;
+  ctx->splitk_override = save_sk;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc) return rc;
+  if (bc < 0) return upk_fail(ctx, UPK_ESHAPE, "autotune: no feasible configuration");
+  *best_cfg = bc;
+  *best_splitk = bs;
+  if (best_us) *best_us = best;
+  if (default_us) *default_us = dflt;
+  return UPK_OK;
 }
 
 extern "C" int upk_gemm_f16(upk_ctx* ctx, const void* A, int lda, int m, int k, const void* w_packed,

@@ -89,20 +89,28 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a, int rows_
   const int C = a.c1 + a.c2;
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
-  if (tid < a.groups) {
-    // fixed-order reduction over chunks: bitwise reproducible
-    double s = 0.0, ss = 0.0;
-    const float* w = a.ws + ((long)b * a.nchunks * a.groups + tid) * 2;
-    for (int k = 0; k < a.nchunks; ++k) {
-      s += w[(long)k * a.groups * 2];
-      ss += w[(long)k * a.groups * 2 + 1];
+  // fixed-order (bitwise reproducible) reduction of the chunk partials, 4 threads per
+  // (group, sum|sumsq) so that the <= 64 loads per quantity are issued in parallel.
+  {
+    __shared__ double part[GN_GROUPS_MAX * 2 * 4];
+    const int q = tid >> 2, sub = tid & 3;  // q = group*2 + which
+    if (q < a.groups * 2) {
+      const float* w = a.ws + (long)b * a.nchunks * a.groups * 2 + q;
+      double acc = 0.0;
+      for (int k = sub; k < a.nchunks; k += 4) acc += (double)w[(long)k * a.groups * 2];
+      part[tid] = acc;
     }
-    const double n = (double)a.hw * a.cpg;
-    const double mean = s / n;
-    double var = ss / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    smean[tid] = (float)mean;
-    srstd[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
+    __syncthreads();
+    if (tid < a.groups) {
+      const double s = ((part[tid * 8 + 0] + part[tid * 8 + 1]) + part[tid * 8 + 2]) + part[tid * 8 + 3];
+      const double ss = ((part[tid * 8 + 4] + part[tid * 8 + 5]) + part[tid * 8 + 6]) + part[tid * 8 + 7];
+      const double n = (double)a.hw * a.cpg;
+      const double mean = s / n;
+      double var = ss / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      smean[tid] = (float)mean;
+      srstd[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
+    }
   }
   __syncthreads();
   float* scale = tab;

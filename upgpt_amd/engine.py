@@ -19,6 +19,8 @@ Design (MI355X-first, not a translation of the reference's nn.Module.forward cha
 PyTorch here = device allocator + stream handle only.
 """
 import ctypes as C
+import json
+import os
 
 import torch
 
@@ -28,6 +30,39 @@ from .arch import UNetArch, VAEArch
 
 def _rup(v, m):
     return (v + m - 1) // m * m
+
+
+class TuneCache:
+    """shape signature -> [cfg, splitk, best_us, default_us], measured on an MI355X by
+    upk_conv_autotune and kept in-tree (upgpt_amd/tuned_gfx950.json) so that fresh processes
+    start with tuned launches.  Unknown shapes fall back to the library's cost model."""
+
+    def __init__(self, path=None):
+        self.path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
+        self.d = {}
+        self.dirty = False
+        if os.path.exists(self.path):
+            try:
+                with open(self.path) as f:
+                    self.d = json.load(f)
+            except Exception:
+                self.d = {}
+
+    def get(self, key):
+        return self.d.get(key)
+
+    def put(self, key, cfg, sk, best_us, dflt_us):
+        self.d[key] = [int(cfg), int(sk), round(float(best_us), 2), round(float(dflt_us), 2)]
+        self.dirty = True
+        return self.d[key]
+
+    def save(self, path=None):
+        with open(path or self.path, "w") as f:
+            json.dump(self.d, f, indent=0, sort_keys=True)
+        self.dirty = False
+
+
+TUNE_CACHE = TuneCache()
 
 
 def head_pad(d):
@@ -149,6 +184,27 @@ class Emitter:
         self.hctx = ctx.h
         self.dev = ctx.device
         self.bufs = []
+        self.convs = []  # (ConvDesc, shape-signature) of every emitted conv, for autotuning
+
+    def apply_tuning(self, cache=None, tune_missing=False, reps=5):
+        """Pins each conv launch to the (tile config, split-K) stored in the tuning cache;
+        with tune_missing=True unknown shapes are timed on the device first
+        (upk_conv_autotune) and added to the cache.  Returns (#hits, #tuned, #missing)."""
+        cache = TUNE_CACHE if cache is None else cache
+        hits = tuned = missing = 0
+        for d, key in self.convs:
+            ent = cache.get(key)
+            if ent is None and tune_missing:
+                cfg, sk, best_us, dflt_us = self.ctx.conv_autotune(d, reps)
+                ent = cache.put(key, cfg, sk, best_us, dflt_us)
+                tuned += 1
+            elif ent is not None:
+                hits += 1
+            else:
+                missing += 1
+            if ent is not None:
+                d.tune_cfg, d.tune_splitk = int(ent[0]) + 1, int(ent[1])
+        return hits, tuned, missing
 
     def alloc(self, *shape, dtype=torch.float16, zero=False):
         t = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=self.dev)
@@ -218,6 +274,8 @@ class Emitter:
             d.vt_from, d.vt_heads, d.vt_dhead = vt["from"], vt["heads"], vt["dhead"]
             d.vt_ld, d.vt_tokens = vt["ld"], vt["tokens"]
         d.flags = flags
+        self.convs.append((d, "M%d_N%d_C%d+%d_k%ds%d_f%x_r%d%d%d" % (
+            M, pw.n_pad, d.c1, d.c2, ks, stride, flags, residual is not None, rowvec is not None, vt is not None)))
         fn, h, ref = self.lib.upk_conv2d_nhwc_f16, self.hctx, C.byref(d)
         chk = self._chk
         P.add(lambda s: chk(fn(h, ref, s)), d, pw, x1, x2, residual, rowvec, out, nchw_out, out_f32, vt)

@@ -3,6 +3,8 @@
 hand-written HIP kernels of libupk.so.  Weights live in a ParamTree with the reference's
 state-dict keys (time_embed.0.weight, input_blocks.1.1.transformer_blocks.0.attn2.to_k.weight,
 out.2.weight, ...)."""
+import os
+
 import torch
 
 from .arch import UNetArch
@@ -75,6 +77,7 @@ class UNetModel(ParamTree):
                 self._plans.pop(next(iter(self._plans)))
             with torch.cuda.device(ctx.device):
                 pl = UNetPlan(ctx, pk, B, H, W, n_ctx, rows, mode)
+                pl.apply_tuning(tune_missing=os.environ.get("UPGPT_AUTOTUNE", "0") == "1")
             self._plans[key] = pl
         return pl
 

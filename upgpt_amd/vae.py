@@ -2,6 +2,8 @@
 decode 330-333) with the Decoder (model.py:462-568) running on libupk.so.  The encoder's
 parameters are held (checkpoint keys first_stage_model.encoder.*) but encode() is a
 "next" row of SURVEY.md §8f and raises until it is built on the same kernels."""
+import os
+
 import torch
 
 from .arch import VAEArch
@@ -61,6 +63,7 @@ class AutoencoderKL(ParamTree):
                 self._plans.pop(next(iter(self._plans)))
             with torch.cuda.device(p.device):
                 self._plans[key] = VAEDecodePlan(ctx, self._packed[1], B, h, w, scale_factor)
+                self._plans[key].apply_tuning(tune_missing=os.environ.get("UPGPT_AUTOTUNE", "0") == "1")
         return self._plans[key]
 
     @torch.no_grad()
