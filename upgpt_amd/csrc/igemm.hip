@@ -142,19 +142,24 @@ struct Epi {
   }
 };
 
-template <int MI, int NI, int WM, int WN>
+// KS = K-chunks (of 32) staged per barrier.  UNet launches have only 1-4 workgroups per CU,
+// so latency must be hidden INSIDE a workgroup: KS chunks of global loads are in flight
+// at once and KS*MI*NI MFMAs run between two barriers.
+template <int MI, int NI, int WM, int WN, int KS>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
   constexpr int BM = MI * 16 * WM;
   constexpr int BN = NI * 16 * WN;
   constexpr int NT = WM * WN * 64;
   constexpr int A_IT = (BM * 4 + NT - 1) / NT;
   constexpr int B_IT = (BN * 4 + NT - 1) / NT;
-  constexpr int A_TILE = BM * 32;  // halfs
+  constexpr int A_TILE = BM * 32;  // halfs per K-chunk
   constexpr int B_TILE = BN * 32;
+  constexpr int A_STAGE = KS * A_TILE;
+  constexpr int B_STAGE = KS * B_TILE;
 
-  __shared__ __attribute__((aligned(16))) f16 smem[2 * (A_TILE + B_TILE)];
-  f16* sA = smem;               // [2][A_TILE]
-  f16* sB = smem + 2 * A_TILE;  // [2][B_TILE]
+  __shared__ __attribute__((aligned(16))) f16 smem[2 * (A_STAGE + B_STAGE)];
+  f16* sA = smem;                // [2][KS][A_TILE]
+  f16* sB = smem + 2 * A_STAGE;  // [2][KS][B_TILE]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -192,55 +197,64 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
     a_ox[i] = (p - oy * a.Wo) * a.stride - a.pad_lo;
   }
 
-  f16x8 ra[A_IT], rb[B_IT];
+  f16x8 ra[KS][A_IT], rb[KS][B_IT];
   const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-  auto load_tiles = [&](int kc) {
-    const int tap = kc / a.cpt;
-    const int c0 = (kc - tap * a.cpt) * 32;
-    const int ky = tap / a.ks;
-    const int kx = tap - ky * a.ks;
-    const bool second = (c0 >= a.c1);
-    const f16* src = second ? a.x2 : a.x1;
-    const int ld = second ? a.ld2 : a.ld1;
-    const int cb = second ? c0 - a.c1 : c0;
+  // issues the global loads of K-chunks [kc, kc + KS) (chunks >= kc1 read as zero)
+  auto load_tiles = [&](int kc_first) {
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      const int q = tid + i * NT;
-      const int ch = q & 3;
-      int iy = a_oy[i] + ky;
-      int ix = a_ox[i] + kx;
-      const bool ok = a_ok[i] && iy >= 0 && iy < a.HL && ix >= 0 && ix < a.WL;
-      if (a.ups) {
-        iy >>= 1;
-        ix >>= 1;
+    for (int s = 0; s < KS; ++s) {
+      const int kc = kc_first + s;
+      const bool live = kc < kc1;
+      const int tap = kc / a.cpt;
+      const int c0 = (kc - tap * a.cpt) * 32;
+      const int ky = tap / a.ks;
+      const int kx = tap - ky * a.ks;
+      const bool second = (c0 >= a.c1);
+      const f16* src = second ? a.x2 : a.x1;
+      const int ld = second ? a.ld2 : a.ld1;
+      const int cb = second ? c0 - a.c1 : c0;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const int q = tid + i * NT;
+        const int ch = q & 3;
+        int iy = a_oy[i] + ky;
+        int ix = a_ox[i] + kx;
+        const bool ok = live && a_ok[i] && iy >= 0 && iy < a.HL && ix >= 0 && ix < a.WL;
+        if (a.ups) {
+          iy >>= 1;
+          ix >>= 1;
+        }
+        const long pix = ((long)a_b[i] * a.HS + iy) * a.WS + ix;
+        ra[s][i] = ok ? *(const f16x8*)(src + pix * ld + cb + ch * 8) : zero8;
       }
-      const long pix = ((long)a_b[i] * a.HS + iy) * a.WS + ix;
-      ra[i] = ok ? *(const f16x8*)(src + pix * ld + cb + ch * 8) : zero8;
-    }
-    const f16* wb = a.w + ((long)kc * a.npad + n0) * 32;
+      const f16* wb = a.w + ((long)kc * a.npad + n0) * 32;
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      const int q = tid + i * NT;
-      const int row = q >> 2;
-      const bool ok = (row < BN) && (n0 + row < a.npad);
-      rb[i] = ok ? *(const f16x8*)(wb + (long)q * 8) : zero8;
+      for (int i = 0; i < B_IT; ++i) {
+        const int q = tid + i * NT;
+        const int row = q >> 2;
+        const bool ok = live && (row < BN) && (n0 + row < a.npad);
+        rb[s][i] = ok ? *(const f16x8*)(wb + (long)q * 8) : zero8;
+      }
     }
   };
   auto store_tiles = [&](int buf) {
-    f16* dA = sA + buf * A_TILE;
-    f16* dB = sB + buf * B_TILE;
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      const int q = tid + i * NT;
-      const int row = q >> 2;
-      if (row < BM) *(f16x8*)(dA + row * 32 + lds_swz(row, q & 3) * 8) = ra[i];
-    }
+    for (int s = 0; s < KS; ++s) {
+      f16* dA = sA + buf * A_STAGE + s * A_TILE;
+      f16* dB = sB + buf * B_STAGE + s * B_TILE;
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      const int q = tid + i * NT;
-      const int row = q >> 2;
-      if (row < BN) *(f16x8*)(dB + row * 32 + lds_swz(row, q & 3) * 8) = rb[i];
+      for (int i = 0; i < A_IT; ++i) {
+        const int q = tid + i * NT;
+        const int row = q >> 2;
+        if (row < BM) *(f16x8*)(dA + row * 32 + lds_swz(row, q & 3) * 8) = ra[s][i];
+      }
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i) {
+        const int q = tid + i * NT;
+        const int row = q >> 2;
+        if (row < BN) *(f16x8*)(dB + row * 32 + lds_swz(row, q & 3) * 8) = rb[s][i];
+      }
     }
   };
 
@@ -261,21 +275,24 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
   }
   __syncthreads();
   int cur = 0;
-  for (int kc = kc0; kc < kc1; ++kc) {
-    const bool more = (kc + 1 < kc1);
-    if (more) load_tiles(kc + 1);
-    const f16* tA = sA + cur * A_TILE + a_base;
-    const f16* tB = sB + cur * B_TILE + b_base;
-    f16x8 fa[MI], fb[NI];
+  for (int kc = kc0; kc < kc1; kc += KS) {
+    const bool more = (kc + KS < kc1);
+    if (more) load_tiles(kc + KS);
 #pragma unroll
-    for (int i = 0; i < MI; ++i) fa[i] = *(const f16x8*)(tA + i * 512);
+    for (int s = 0; s < KS; ++s) {
+      const f16* tA = sA + cur * A_STAGE + s * A_TILE + a_base;
+      const f16* tB = sB + cur * B_STAGE + s * B_TILE + b_base;
+      f16x8 fa[MI], fb[NI];
 #pragma unroll
-    for (int j = 0; j < NI; ++j) fb[j] = *(const f16x8*)(tB + j * 512);
+      for (int i = 0; i < MI; ++i) fa[i] = *(const f16x8*)(tA + i * 512);
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+      for (int j = 0; j < NI; ++j) fb[j] = *(const f16x8*)(tB + j * 512);
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
     if (more) store_tiles(cur ^ 1);
     __syncthreads();
     cur ^= 1;
@@ -342,37 +359,38 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmArgs a, in
 }
 
 struct CfgInfo {
-  int mi, ni, wm, wn;
+  int mi, ni, wm, wn, ks;
   const char* name;
   void (*fn)(const IgemmArgs);
 };
 
-#define CFG(MI, NI, WM, WN) {MI, NI, WM, WN, #MI "x" #NI "x" #WM "x" #WN, igemm_kernel<MI, NI, WM, WN>}
-// (MI, NI, WM, WN): block tile = (MI*16*WM) x (NI*16*WN), WM*WN waves.
+#define CFG(MI, NI, WM, WN, KS) \
+  {MI, NI, WM, WN, KS, #MI "x" #NI "x" #WM "x" #WN "k" #KS, igemm_kernel<MI, NI, WM, WN, KS>}
+// (MI, NI, WM, WN, KS): block tile = (MI*16*WM) x (NI*16*WN), WM*WN waves, KS K-chunks/stage.
 const CfgInfo kCfgs[] = {
-    CFG(4, 4, 2, 2),  // 0: 128x128
-    CFG(2, 4, 2, 2),  // 1:  64x128
-    CFG(4, 2, 2, 2),  // 2: 128x64
-    CFG(2, 2, 2, 2),  // 3:  64x64
-    CFG(2, 4, 4, 1),  // 4: 128x64   (wave 32x64, GEGLU capable)
-    CFG(1, 4, 4, 1),  // 5:  64x64   (wave 16x64, GEGLU capable)
-    CFG(4, 7, 2, 2),  // 6: 128x224  (7-family: 224 = 7*32)
-    CFG(2, 7, 2, 2),  // 7:  64x224
-    CFG(1, 7, 2, 2),  // 8:  32x224
-    CFG(2, 7, 4, 1),  // 9: 128x112
-    CFG(1, 7, 4, 1),  // 10: 64x112
-    CFG(1, 7, 2, 1),  // 11: 32x112  (2 waves)
-    CFG(2, 1, 4, 1),  // 12: 128x16  (N <= 16: UNet/VAE output convs)
-    CFG(1, 2, 4, 1),  // 13: 64x32
-    CFG(1, 4, 1, 4),  // 14: 16x256  (tiny M: emb / context projections)
-    CFG(1, 2, 2, 2),  // 15: 32x64
+    CFG(4, 4, 2, 2, 1), CFG(4, 4, 2, 2, 2),  // 128x128
+    CFG(2, 4, 2, 2, 1), CFG(2, 4, 2, 2, 2),  //  64x128
+    CFG(4, 2, 2, 2, 1), CFG(4, 2, 2, 2, 2),  // 128x64
+    CFG(2, 2, 2, 2, 1), CFG(2, 2, 2, 2, 4),  //  64x64
+    CFG(2, 4, 4, 1, 1), CFG(2, 4, 4, 1, 2),  // 128x64   (wave 32x64, GEGLU capable)
+    CFG(1, 4, 4, 1, 1), CFG(1, 4, 4, 1, 4),  //  64x64   (wave 16x64, GEGLU capable)
+    CFG(4, 7, 2, 2, 1), CFG(4, 7, 2, 2, 2),  // 128x224  (7-family: 224 = 7*32)
+    CFG(2, 7, 2, 2, 1), CFG(2, 7, 2, 2, 2),  //  64x224
+    CFG(1, 7, 2, 2, 1), CFG(1, 7, 2, 2, 2),  //  32x224
+    CFG(2, 7, 4, 1, 1), CFG(2, 7, 4, 1, 2),  // 128x112
+    CFG(1, 7, 4, 1, 1), CFG(1, 7, 4, 1, 2), CFG(1, 7, 4, 1, 4),  // 64x112
+    CFG(1, 7, 2, 1, 1), CFG(1, 7, 2, 1, 4),  //  32x112  (2 waves)
+    CFG(2, 1, 4, 1, 1), CFG(2, 1, 4, 1, 4),  // 128x16   (N <= 16: UNet/VAE output convs)
+    CFG(1, 2, 4, 1, 1), CFG(1, 2, 4, 1, 4), CFG(1, 2, 4, 1, 8),  // 64x32
+    CFG(1, 4, 1, 4, 1), CFG(1, 4, 1, 4, 2),  //  16x256  (tiny M: emb / context projections)
+    CFG(1, 2, 2, 2, 1), CFG(1, 2, 2, 2, 4), CFG(1, 2, 2, 2, 8),  // 32x64
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// Rough cycle model used to pick (config, split-K). Tuned on MI355X; override with
-// upk_conv_override for experiments.
+// Rough cycle model used to pick (config, split-K) for shapes that are not in the tuning
+// cache (upgpt_amd/tuned_gfx950.json holds measured choices for the bench shapes).
 double estimate(const CfgInfo& c, int M, int npad, int nchunks, int splitk, int cus, bool geglu) {
   const int BM = c.mi * 16 * c.wm, BN = c.ni * 16 * c.wn;
   const int waves = c.wm * c.wn;
@@ -380,25 +398,31 @@ double estimate(const CfgInfo& c, int M, int npad, int nchunks, int splitk, int 
   const int tiles = cdiv(M, BM) * cdiv(npad, BN);
   const long wgs = (long)tiles * splitk;
   const int chunks = cdiv(nchunks, splitk);
+  const int stages = cdiv(chunks, c.ks);
   // per K-chunk cycles of one workgroup
   const double mfma = c.mi * c.ni * 16.0 * (waves > 4 ? waves / 4.0 : 1.0);
   const double lds = (c.mi + c.ni) * 4.0 * waves + (BM + BN) * 4 * 13.0 / 64.0 / 4.0;
   const double gl = (BM + BN) * 64.0 / 40.0;  // bytes / (B/clk/CU sustained from L2)
-  double per_chunk = fmax(fmax(mfma, lds), gl) + 90.0;  // + barrier / issue overhead
+  const double work = fmax(fmax(mfma, lds), gl) * c.ks;
   // workgroups resident per CU (LDS + registers), they overlap each other's stalls
-  const int lds_bytes = 2 * (BM + BN) * 64;
+  const int lds_bytes = 2 * c.ks * (BM + BN) * 64;
   int occ = 160 * 1024 / lds_bytes;
-  const int regs = c.mi * c.ni * 4 + (c.mi + c.ni) * 8 + 40;
+  const int nt = waves * 64;
+  const int stage_regs = c.ks * (cdiv(BM * 4, nt) + cdiv(BN * 4, nt)) * 4;
+  const int regs = c.mi * c.ni * 4 + (c.mi + c.ni) * 8 + stage_regs + 40;
   int occ_r = (512 / regs) * 4 / waves;
   if (occ_r < 1) occ_r = 1;
   if (occ > occ_r) occ = occ_r;
   if (occ > 4) occ = 4;
+  if (occ < 1) occ = 1;
   const double slots = (double)cus * occ;
   const double rounds = ceil(wgs / slots);
-  // co-resident workgroups share the CU: each runs ~occ x slower but hides latency
-  const double eff = (occ >= 2) ? 0.75 : 1.0;
-  double t = rounds * (chunks * per_chunk * occ * eff + 1500.0);
-  if (splitk > 1) t += 4000.0 + (double)M * npad * splitk * 4.0 / (cus * 40.0);
+  const long resident = wgs < (long)slots ? (wgs + cus - 1) / cus : occ;  // WGs actually sharing a CU
+  // one stage: its own work (shared with co-resident WGs) or the exposed load latency
+  const double latency = 1400.0;
+  const double per_stage = fmax(work * (double)resident, latency) + 150.0;
+  double t = rounds * (stages * per_stage + 2500.0);
+  if (splitk > 1) t += 6000.0 + (double)M * npad * splitk * 8.0 / (cus * 8.0);
   return t;
 }
 

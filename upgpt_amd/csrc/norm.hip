@@ -201,8 +201,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* x, int ldx, i
 }
 
 inline int gn_chunks(int hw) {
-  int n = (hw + 31) / 32;
-  if (n > GN_MAX_CHUNKS) n = GN_MAX_CHUNKS;
+  // as many chunks (= workgroups per sample) as the partial buffer allows: the deep UNet levels
+  // have only 16..64 pixels per sample and would otherwise run on a handful of CUs
+  int n = hw < GN_MAX_CHUNKS ? hw : GN_MAX_CHUNKS;
   if (n < 1) n = 1;
   return n;
 }
