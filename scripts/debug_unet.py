@@ -1,7 +1,7 @@
 """GPU debug: product UNet forward vs the CPU oracle, per block (dev tool)."""
 import sys, time
 import torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import upgpt_amd
 from upgpt_amd import synth
 from oracle import unet as o_unet

@@ -1,6 +1,6 @@
 """Measures the per-kernel floor: N dependent trivial kernels, eager vs HIP-graph replay."""
 import sys, time, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from upgpt_amd._lib import get_context
 ctx = get_context(0)
 step = torch.zeros(1, dtype=torch.int32, device="cuda")

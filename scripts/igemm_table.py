@@ -1,7 +1,7 @@
 """Per-(tile config, split-K) timing table for representative UNet conv/GEMM shapes (dev tool)."""
 import sys, math, ctypes as C
 import torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from upgpt_amd import _lib as L
 ctx = L.get_context(0)
 lib = ctx.lib

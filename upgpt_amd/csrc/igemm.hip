@@ -18,9 +18,14 @@
 //     deterministic reduce+epilogue kernel (deep UNet levels have M = 96..384 rows only).
 //
 // Replaces F.conv2d / F.linear at the call sites listed in include/upk.h.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
+
+// debug-only ablation bits (env UPK_ABLATE, read per launch): which phase owns the time?
+enum { ABL_NOEPI = 0x10000, ABL_NOGLOAD = 0x20000, ABL_NOLDSW = 0x40000, ABL_NOMFMA = 0x80000 };
 
 struct IgemmArgs {
   const f16* x1;
@@ -58,85 +63,103 @@ struct IgemmArgs {
 // 256-B bank row.
 __device__ __forceinline__ int lds_swz(int row, int chunk) { return chunk ^ ((-(row >> 2)) & 3); }
 
+// Epilogue, split in a per-ROW part (integer division for the sample index, row offsets:
+// once per 16-row fragment) and a per-4-COLUMN part, with 32-bit offsets against uniform
+// base pointers — with K loops as short as 7..16 chunks the epilogue is a large share of
+// the issued instructions, so it is kept lean.
+struct RowCtx {
+  bool ok;
+  unsigned y_off, res_off, rv_off, vt_off, nchw_off;
+};
+
 struct Epi {
-  // Applies bias / rowvec / activation / residual and stores 4 consecutive packed
-  // columns [n, n+4) of row m. v = value accumulators, g = gate accumulators (GEGLU).
-  static __device__ __forceinline__ void store(const IgemmArgs& a, int m, int n, f32x4 v, f32x4 g) {
-    if (m >= a.M) return;
+  static __device__ __forceinline__ RowCtx row(const IgemmArgs& a, int m) {
+    RowCtx r;
+    r.ok = m < a.M;
+    const int mm = r.ok ? m : 0;
+    r.y_off = (unsigned)mm * (unsigned)a.ldy;
+    r.res_off = (unsigned)mm * (unsigned)a.ldr;
+    r.rv_off = 0;
+    r.vt_off = 0;
+    r.nchw_off = 0;
+    if (a.rowvec || (a.flags & UPK_F_OUT_NCHW_F32)) {
+      const int hw = a.Ho * a.Wo;
+      const int b = mm / hw;
+      const int p = mm - b * hw;
+      const int st = (a.rowvec && a.step) ? *a.step : 0;
+      r.rv_off = (unsigned)(st * a.rv_ss + b * a.rv_bs);
+      r.nchw_off = (unsigned)(b * a.n_out * hw + p);
+    }
+    if (a.vt) {
+      const int bb = mm / a.vt_tokens;
+      const int tok = mm - bb * a.vt_tokens;
+      r.vt_off = (unsigned)(bb * a.vt_heads * a.vt_dhead * a.vt_ld + tok);
+    }
+    return r;
+  }
+
+  // stores packed columns [n, n+4) of the row; v = value accumulators, g = gate (GEGLU)
+  static __device__ __forceinline__ void store(const IgemmArgs& a, const RowCtx& r, int n, f32x4 v, f32x4 g) {
+    if (!r.ok) return;
     const int flags = a.flags;
     int oc = n;  // output column
     if (flags & UPK_F_GEGLU) {
       // packed rows: [32 value | 32 gate] per 64-row block
       if (a.bias) {
-        f32x4 bv = *(const f32x4*)(a.bias + n);
-        f32x4 bg = *(const f32x4*)(a.bias + n + 32);
-        v += bv;
-        g += bg;
+        v += *(const f32x4*)(a.bias + n);
+        g += *(const f32x4*)(a.bias + n + 32);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = v[r] * upk_gelu(g[r]);
+      for (int k = 0; k < 4; ++k) v[k] = v[k] * upk_gelu(g[k]);
       oc = (n >> 6) * 32 + (n & 31);
-    } else {
-      if (a.bias) v += *(const f32x4*)(a.bias + n);
+    } else if (a.bias) {
+      v += *(const f32x4*)(a.bias + n);
     }
-    if (oc >= a.n_out && !(a.vt && n >= a.vt_from)) return;
-    int b = 0, p = m;
-    if (a.rowvec || (flags & UPK_F_OUT_NCHW_F32)) {
-      const int hw = a.Ho * a.Wo;
-      b = m / hw;
-      p = m - b * hw;
-    }
-    if (a.rowvec) {
-      const int st = a.step ? *a.step : 0;
-      const float* rv = a.rowvec + (long)st * a.rv_ss + (long)b * a.rv_bs + n;
-      v += *(const f32x4*)rv;
-    }
+    const bool to_vt = a.vt && n >= a.vt_from;
+    if (oc >= a.n_out && !to_vt) return;
+    if (a.rowvec) v += *(const f32x4*)(a.rowvec + r.rv_off + n);
     if (flags & UPK_F_SILU) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = upk_silu(v[r]);
+      for (int k = 0; k < 4; ++k) v[k] = upk_silu(v[k]);
     }
-    if (a.vt && n >= a.vt_from) {
-      const int cc = n - a.vt_from;
-      const int h = cc / a.vt_dhead;
-      const int d = cc - h * a.vt_dhead;
-      const int bb = m / a.vt_tokens;
-      const int tok = m - bb * a.vt_tokens;
-      f16* dst = a.vt + ((long)(bb * a.vt_heads + h) * a.vt_dhead + d) * a.vt_ld + tok;
+    if (to_vt) {
+      const int cc = n - a.vt_from;  // = h * dhead + d  ->  row (h*dhead + d) of this sample's V^T
+      f16* dst = a.vt + r.vt_off + (unsigned)cc * (unsigned)a.vt_ld;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dst[(long)r * a.vt_ld] = (f16)v[r];
+      for (int k = 0; k < 4; ++k) dst[(unsigned)k * (unsigned)a.vt_ld] = (f16)v[k];
       return;
     }
     if (a.res) {
-      f16x4 rr = *(const f16x4*)(a.res + (long)m * a.ldr + oc);
+      const f16x4 rr = *(const f16x4*)(a.res + r.res_off + oc);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+      for (int k = 0; k < 4; ++k) v[k] += (float)rr[k];
     }
     if (flags & UPK_F_OUT_NCHW_F32) {
-      float* yo = (float*)a.y;
-      const long hw = (long)a.Ho * a.Wo;
+      float* yo = (float*)a.y + r.nchw_off;
+      const unsigned hw = (unsigned)(a.Ho * a.Wo);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (oc + r < a.n_out) yo[((long)b * a.n_out + oc + r) * hw + p] = v[r];
+      for (int k = 0; k < 4; ++k)
+        if (oc + k < a.n_out) yo[(unsigned)(oc + k) * hw] = v[k];
     } else if (flags & UPK_F_OUT_F32) {
-      float* yo = (float*)a.y + (long)m * a.ldy + oc;
+      float* yo = (float*)a.y + r.y_off + oc;
       if (oc + 3 < a.n_out) {
         *(f32x4*)yo = v;
       } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (oc + r < a.n_out) yo[r] = v[r];
+        for (int k = 0; k < 4; ++k)
+          if (oc + k < a.n_out) yo[k] = v[k];
       }
     } else {
-      f16* yo = (f16*)a.y + (long)m * a.ldy + oc;
+      f16* yo = (f16*)a.y + r.y_off + oc;
       if (oc + 3 < a.n_out) {
         f16x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (f16)v[r];
+        for (int k = 0; k < 4; ++k) o[k] = (f16)v[k];
         *(f16x4*)yo = o;
       } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (oc + r < a.n_out) yo[r] = (f16)v[r];
+        for (int k = 0; k < 4; ++k)
+          if (oc + k < a.n_out) yo[k] = (f16)v[k];
       }
     }
   }
@@ -200,41 +223,70 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
   f16x8 ra[KS][A_IT], rb[KS][B_IT];
   const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-  // issues the global loads of K-chunks [kc, kc + KS) (chunks >= kc1 read as zero)
-  auto load_tiles = [&](int kc_first) {
+  // ---- K cursor: next chunk to load <-> (ky, kx, c0).  Kept incrementally (no integer
+  // divisions in the loop) and the per-row pixel pointers are recomputed only when the
+  // filter tap changes: the address math was costing ~14 VALU+SALU issues per MFMA.
+  const int ctot = a.c1 + a.c2;
+  int cur_kc = kc0, cur_c0, cur_ky, cur_kx;
+  {
+    const int tap = kc0 / a.cpt;
+    cur_c0 = (kc0 - tap * a.cpt) * 32;
+    cur_ky = tap / a.ks;
+    cur_kx = tap - cur_ky * a.ks;
+  }
+  const f16* ap1[A_IT];
+  const f16* ap2[A_IT];
+  bool tap_ok[A_IT];
+  auto set_tap = [&](int ky, int kx) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int ch = (tid + i * NT) & 3;
+      int iy = a_oy[i] + ky;
+      int ix = a_ox[i] + kx;
+      tap_ok[i] = a_ok[i] && iy >= 0 && iy < a.HL && ix >= 0 && ix < a.WL;
+      if (a.ups) {
+        iy >>= 1;
+        ix >>= 1;
+      }
+      const long pix = tap_ok[i] ? ((long)a_b[i] * a.HS + iy) * a.WS + ix : 0;
+      ap1[i] = a.x1 + pix * a.ld1 + ch * 8;
+      ap2[i] = a.x2 ? a.x2 + pix * a.ld2 + ch * 8 - a.c1 : a.x1;
+    }
+  };
+  set_tap(cur_ky, cur_kx);
+  bool b_ok[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int row = (tid + i * NT) >> 2;
+    b_ok[i] = (row < BN) && (n0 + row < a.npad);
+  }
+  const f16* wcur = a.w + ((long)kc0 * a.npad + n0) * 32 + tid * 8;  // + i*NT*8 per B_IT
+  const long wstep = (long)a.npad * 32;
+
+  // issues the global loads of the next KS K-chunks (chunks >= kc1 read as zero)
+  auto load_tiles = [&]() {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const int kc = kc_first + s;
-      const bool live = kc < kc1;
-      const int tap = kc / a.cpt;
-      const int c0 = (kc - tap * a.cpt) * 32;
-      const int ky = tap / a.ks;
-      const int kx = tap - ky * a.ks;
-      const bool second = (c0 >= a.c1);
-      const f16* src = second ? a.x2 : a.x1;
-      const int ld = second ? a.ld2 : a.ld1;
-      const int cb = second ? c0 - a.c1 : c0;
+      const bool live = cur_kc < kc1;
+      const bool second = cur_c0 >= a.c1;
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
-        const int q = tid + i * NT;
-        const int ch = q & 3;
-        int iy = a_oy[i] + ky;
-        int ix = a_ox[i] + kx;
-        const bool ok = live && a_ok[i] && iy >= 0 && iy < a.HL && ix >= 0 && ix < a.WL;
-        if (a.ups) {
-          iy >>= 1;
-          ix >>= 1;
-        }
-        const long pix = ((long)a_b[i] * a.HS + iy) * a.WS + ix;
-        ra[s][i] = ok ? *(const f16x8*)(src + pix * ld + cb + ch * 8) : zero8;
+        const f16* p = (second ? ap2[i] : ap1[i]) + cur_c0;
+        ra[s][i] = (live && tap_ok[i]) ? *(const f16x8*)p : zero8;
       }
-      const f16* wb = a.w + ((long)kc * a.npad + n0) * 32;
 #pragma unroll
-      for (int i = 0; i < B_IT; ++i) {
-        const int q = tid + i * NT;
-        const int row = q >> 2;
-        const bool ok = live && (row < BN) && (n0 + row < a.npad);
-        rb[s][i] = ok ? *(const f16x8*)(wb + (long)q * 8) : zero8;
+      for (int i = 0; i < B_IT; ++i)
+        rb[s][i] = (live && b_ok[i]) ? *(const f16x8*)(wcur + i * (NT * 8)) : zero8;
+      wcur += wstep;
+      ++cur_kc;
+      cur_c0 += 32;
+      if (cur_c0 == ctot) {
+        cur_c0 = 0;
+        if (++cur_kx == a.ks) {
+          cur_kx = 0;
+          ++cur_ky;
+        }
+        if (cur_kc < kc1) set_tap(cur_ky, cur_kx);
       }
     }
   };
@@ -270,14 +322,14 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
   const int b_base = wn * (NI * 16) * 32 + frag_off;
 
   if (kc0 < kc1) {
-    load_tiles(kc0);
+    load_tiles();
     store_tiles(0);
   }
   __syncthreads();
   int cur = 0;
   for (int kc = kc0; kc < kc1; kc += KS) {
     const bool more = (kc + KS < kc1);
-    if (more) load_tiles(kc + KS);
+    if (more && !(a.flags & ABL_NOGLOAD)) load_tiles();
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const f16* tA = sA + cur * A_STAGE + s * A_TILE + a_base;
@@ -287,13 +339,20 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
       for (int i = 0; i < MI; ++i) fa[i] = *(const f16x8*)(tA + i * 512);
 #pragma unroll
       for (int j = 0; j < NI; ++j) fb[j] = *(const f16x8*)(tB + j * 512);
+      if (!(a.flags & ABL_NOMFMA)) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(fb[j]));
+      }
     }
-    if (more) store_tiles(cur ^ 1);
+    if (more && !(a.flags & ABL_NOLDSW)) store_tiles(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
@@ -301,33 +360,43 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
   // ---- epilogue: lane (lg, lc) holds rows m = .. + lc, cols n = .. + 4*lg + r ----
   const int mw = m0 + wm * (MI * 16);
   const int nw = n0 + wn * (NI * 16);
+  if (a.flags & ABL_NOEPI) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (t == 123.456f) ((float*)a.y)[0] = t;
+    return;
+  }
   if (a.partial) {
-    float* slab = a.partial + (long)blockIdx.z * a.M * a.npad;
+    float* slab = a.partial + (long)blockIdx.z * a.M * a.npad;  // uniform base
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = mw + i * 16 + lc;
       if (m >= a.M) continue;
+      const unsigned roff = (unsigned)m * (unsigned)a.npad;
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const int n = nw + j * 16 + lg * 4;
-        if (n < a.npad) *(f32x4*)(slab + (long)m * a.npad + n) = acc[i][j];
+        if (n < a.npad) *(f32x4*)(slab + roff + n) = acc[i][j];
       }
     }
     return;
   }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const int m = mw + i * 16 + lc;
+    const RowCtx rc = Epi::row(a, mw + i * 16 + lc);
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int n = nw + j * 16 + lg * 4;
       if (n >= a.npad) continue;
       if (a.flags & UPK_F_GEGLU) {
         if constexpr (NI % 4 == 0) {
-          if ((j & 2) == 0) Epi::store(a, m, n, acc[i][j], acc[i][j + 2 < NI ? j + 2 : j]);
+          if ((j & 2) == 0) Epi::store(a, rc, n, acc[i][j], acc[i][j + 2 < NI ? j + 2 : j]);
         }
       } else {
-        Epi::store(a, m, n, acc[i][j], acc[i][j]);
+        Epi::store(a, rc, n, acc[i][j], acc[i][j]);
       }
     }
   }
@@ -355,7 +424,7 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmArgs a, in
   }
   IgemmArgs b = a;
   b.partial = nullptr;
-  Epi::store(b, m, n, v, g);
+  Epi::store(b, Epi::row(b, m), n, v, g);
 }
 
 struct CfgInfo {
@@ -508,6 +577,7 @@ extern "C" int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_str
   a.cpt = (a.c1 + a.c2) / 32;
   a.nchunks = a.ks * a.ks * a.cpt;
   a.flags = flags;
+  if (const char* ab = getenv("UPK_ABLATE")) a.flags |= (int)strtol(ab, nullptr, 0) & 0xF0000;
 
   // ---- choose config + split-K ----
   int best = -1, best_sk = 1;

@@ -159,18 +159,26 @@ class Program:
     def __init__(self, ctx):
         self.ctx = ctx
         self.ops = []
+        self.cls = []
         self.keep = []
         self.igemm_flops = 0
         self.attn_flops = 0
         self.n_launch = 0
 
-    def run(self, stream=None):
+    def run(self, stream=None, skip=()):
+        """skip: op classes to leave out (ablation timing only: results are garbage)."""
         s = self.ctx._s() if stream is None else stream
+        if skip:
+            for op, cls in zip(self.ops, self.cls):
+                if cls not in skip:
+                    op(s)
+            return
         for op in self.ops:
             op(s)
 
-    def add(self, fn, *keep):
+    def add(self, fn, *keep, cls="other"):
         self.ops.append(fn)
+        self.cls.append(cls)
         self.keep.extend(keep)
         self.n_launch += 1
 
@@ -278,7 +286,8 @@ class Emitter:
             M, pw.n_pad, d.c1, d.c2, ks, stride, flags, residual is not None, rowvec is not None, vt is not None)))
         fn, h, ref = self.lib.upk_conv2d_nhwc_f16, self.hctx, C.byref(d)
         chk = self._chk
-        P.add(lambda s: chk(fn(h, ref, s)), d, pw, x1, x2, residual, rowvec, out, nchw_out, out_f32, vt)
+        P.add(lambda s: chk(fn(h, ref, s)), d, pw, x1, x2, residual, rowvec, out, nchw_out, out_f32, vt,
+              cls="igemm_k%d" % ks)
         P.igemm_flops += 2 * M * pw.n_real * pw.k_real
         return ret
 
@@ -289,7 +298,7 @@ class Emitter:
         a = (x1.t.data_ptr(), x1.C, x1.ld, x2.t.data_ptr() if x2 is not None else None, x2.C if x2 is not None else 0,
              x2.ld if x2 is not None else 0, x1.B, x1.H * x1.W, 32, gamma.data_ptr(), beta.data_ptr(), float(eps),
              int(bool(silu)), y.t.data_ptr(), y.ld, ws.data_ptr())
-        P.add(lambda s: chk(fn(h, *a, s)), x1, x2, gamma, beta, y, ws)
+        P.add(lambda s: chk(fn(h, *a, s)), x1, x2, gamma, beta, y, ws, cls="groupnorm")
         P.n_launch += 1  # stats + apply
         return y
 
@@ -297,14 +306,14 @@ class Emitter:
         y = Act(self.alloc(x.M, x.C), x.B, x.H, x.W, x.C)
         fn, h, chk = self.lib.upk_layernorm_f16, self.hctx, self._chk
         a = (x.t.data_ptr(), x.ld, x.M, x.C, gamma.data_ptr(), beta.data_ptr(), float(eps), y.t.data_ptr(), y.ld)
-        P.add(lambda s: chk(fn(h, *a, s)), x, gamma, beta, y)
+        P.add(lambda s: chk(fn(h, *a, s)), x, gamma, beta, y, cls="layernorm")
         return y
 
     def attention(self, P, q, ldq, qbs, k, ldk, kbs, vt, vt_ld, out, ldo, obs, B, heads, nq, nkv, dp, scale):
         fn, h, chk = self.lib.upk_attention_f16, self.hctx, self._chk
         a = (q.data_ptr(), ldq, qbs, k.data_ptr(), ldk, kbs, vt.data_ptr(), vt_ld, out.data_ptr(), ldo, obs, B, heads,
              nq, nkv, dp, float(scale))
-        P.add(lambda s: chk(fn(h, *a, s)), q, k, vt, out)
+        P.add(lambda s: chk(fn(h, *a, s)), q, k, vt, out, cls="attention")
 
 
 # ====================================================================== UNet
