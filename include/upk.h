@@ -158,7 +158,7 @@ const char* upk_conv_config_name(int cfg);
  * k  : fp16 [B, n_kv, ldk ] same head layout, batch stride = k_batch_stride elements
  * vt : fp16 [B, heads, d, vt_ld] (V transposed, vt_ld >= round_up(n_kv,32), zero padded)
  * out: fp16 [B, n_q , ldo ]
- * d in {32, 64, 128, 512} (head dims are padded to these by weight packing). */
+ * d in {32, 64, 128, 256, 512} (head dims are padded to these by weight packing). */
 int upk_attention_f16(upk_ctx* ctx, const void* q, int ldq, long long q_batch_stride,
                       const void* k, int ldk, long long k_batch_stride, const void* vt, int vt_ld,
                       void* out, int ldo, long long o_batch_stride, int batch, int heads, int n_q,

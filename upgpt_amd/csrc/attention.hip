@@ -28,6 +28,95 @@ struct AttnArgs {
   float scale_log2;  // scale * log2(e)
 };
 
+// One K/V tile of NS*16 keys for the 16 queries of this wave (NS = 4 in the main loop, 2 for
+// the tail).  Scores stay unscaled; softmax uses exp2(s*c - m*c) with c = scale*log2(e) folded
+// into one FMA per score.  V^T fragments are requested before the softmax arithmetic so
+// their latency hides under it.
+template <int D, int QREG, int NS>
+__device__ __forceinline__ void attn_tile(const AttnArgs& a, const f16* qrow, bool q_ok, const f16x8* qf,
+                                          const f16* kbase, const f16* vbase, int kb, int g, int c,
+                                          f32x4* o, float& mrun, float& lrun) {
+  constexpr int KD = D / 32;
+  constexpr int DT = D / 16;
+  constexpr int NC = NS / 2;  // 32-key chunks for the PV MFMAs
+  const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  f32x4 s[NS];
+  const f16* kp[NS];
+#pragma unroll
+  for (int t = 0; t < NS; ++t) {
+    s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int key = kb + 16 * t + c;
+    kp[t] = kbase + (long)(key < a.nkv ? key : 0) * a.ldk;
+  }
+#pragma unroll
+  for (int kd = 0; kd < KD; ++kd) {
+    const f16x8 qv = QREG ? qf[kd] : (q_ok ? *(const f16x8*)(qrow + kd * 32) : zero8);
+#pragma unroll
+    for (int t = 0; t < NS; ++t)
+      s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const f16x8*)(kp[t] + kd * 32), qv, s[t], 0, 0, 0);
+  }
+  // V^T operand fragments (only when they fit in registers next to the accumulators)
+  constexpr bool VPRE = (D <= 128);
+  f16x4 vpre[VPRE ? DT * NC * 2 : 1];
+  if (VPRE) {
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        const f16* vr = vbase + (long)i * 16 * a.vt_ld + kb + 32 * j;
+        vpre[(i * NC + j) * 2] = *(const f16x4*)vr;
+        vpre[(i * NC + j) * 2 + 1] = *(const f16x4*)(vr + 16);
+      }
+  }
+  // lane (g, c) holds keys kb + 16t + 4g + r of query c
+  float mx = -INFINITY;
+  if (kb + NS * 16 > a.nkv) {  // tail tile: mask keys beyond n_kv (wave-uniform branch)
+#pragma unroll
+    for (int t = 0; t < NS; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (kb + 16 * t + 4 * g + r >= a.nkv) s[t][r] = -INFINITY;
+  }
+#pragma unroll
+  for (int t = 0; t < NS; ++t) mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  const float cs = a.scale_log2;
+  const float mnew = fmaxf(mrun, mx);  // finite: every tile has >= 1 valid key
+  const float alpha = exp2f((mrun - mnew) * cs);
+  mrun = mnew;
+  const float mc = -mnew * cs;
+  f16x8 pf[NC];
+  float ps = 0.f;
+#pragma unroll
+  for (int t = 0; t < NS; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float p = exp2f(fmaf(s[t][r], cs, mc));
+      ps += p;
+      pf[t >> 1][(t & 1) * 4 + r] = (f16)p;
+    }
+  lrun = lrun * alpha + ps;
+#pragma unroll
+  for (int i = 0; i < DT; ++i) o[i] *= alpha;
+#pragma unroll
+  for (int i = 0; i < DT; ++i)
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      f16x4 va, vb;
+      if (VPRE) {
+        va = vpre[(i * NC + j) * 2];
+        vb = vpre[(i * NC + j) * 2 + 1];
+      } else {
+        const f16* vr = vbase + (long)i * 16 * a.vt_ld + kb + 32 * j;
+        va = *(const f16x4*)vr;
+        vb = *(const f16x4*)(vr + 16);
+      }
+      const f16x8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+      o[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[j], o[i], 0, 0, 0);
+    }
+}
+
 template <int D, int QREG>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   constexpr int KD = D / 32;  // k-steps of Q K^T
@@ -57,55 +146,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   for (int i = 0; i < DT; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float mrun = -INFINITY, lrun = 0.f;
 
-  for (int kb = 0; kb < a.nkv; kb += 32) {
-    f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
-    const int key0 = kb + c, key1 = kb + 16 + c;
-    const f16* k0p = kbase + (long)(key0 < a.nkv ? key0 : 0) * a.ldk;
-    const f16* k1p = kbase + (long)(key1 < a.nkv ? key1 : 0) * a.ldk;
-#pragma unroll
-    for (int kd = 0; kd < KD; ++kd) {
-      const f16x8 qv = QREG ? qf[kd] : (q_ok ? *(const f16x8*)(qrow + kd * 32) : zero8);
-      const f16x8 ka = *(const f16x8*)(k0p + kd * 32);
-      const f16x8 kc = *(const f16x8*)(k1p + kd * 32);
-      s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qv, s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kc, qv, s1, 0, 0, 0);
-    }
-    // lane holds keys kb + 4g + r (s0) and kb + 16 + 4g + r (s1) of query c
-    float sv[8];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ka = kb + 4 * g + r;
-      sv[r] = (ka < a.nkv) ? s0[r] * a.scale_log2 : -INFINITY;
-      sv[4 + r] = (ka + 16 < a.nkv) ? s1[r] * a.scale_log2 : -INFINITY;
-      mx = fmaxf(mx, fmaxf(sv[r], sv[4 + r]));
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float mnew = fmaxf(mrun, mx);  // finite: every 32-key tile has >= 1 valid key
-    const float alpha = exp2f(mrun - mnew);
-    mrun = mnew;
-    f16x8 pf;
-    float ps = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float p = exp2f(sv[e] - mnew);
-      ps += p;
-      pf[e] = (f16)p;
-    }
-    lrun = lrun * alpha + ps;
-#pragma unroll
-    for (int i = 0; i < DT; ++i) o[i] *= alpha;
-    const f16* vp = vbase + kb;
-#pragma unroll
-    for (int i = 0; i < DT; ++i) {
-      const f16* vr = vp + (long)i * 16 * a.vt_ld;
-      const f16x4 va = *(const f16x4*)(vr);
-      const f16x4 vb = *(const f16x4*)(vr + 16);
-      const f16x8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
-      o[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[i], 0, 0, 0);
-    }
+  int kb = 0;
+  if (D <= 128) {  // 64-key tiles while they are full; the 32-key form handles the rest
+    for (; kb + 64 <= a.nkv; kb += 64) attn_tile<D, QREG, 4>(a, qrow, q_ok, qf, kbase, vbase, kb, g, c, o, mrun, lrun);
   }
+  for (; kb < a.nkv; kb += 32) attn_tile<D, QREG, 2>(a, qrow, q_ok, qf, kbase, vbase, kb, g, c, o, mrun, lrun);
+
   lrun += __shfl_xor(lrun, 16);
   lrun += __shfl_xor(lrun, 32);
   const float inv = 1.0f / lrun;
@@ -154,8 +200,9 @@ extern "C" int upk_attention_f16(upk_ctx* ctx, const void* q, int ldq, long long
     case 32: hipLaunchKernelGGL((attn_kernel<32, 1>), grid, block, 0, stream, a); break;
     case 64: hipLaunchKernelGGL((attn_kernel<64, 1>), grid, block, 0, stream, a); break;
     case 128: hipLaunchKernelGGL((attn_kernel<128, 1>), grid, block, 0, stream, a); break;
+    case 256: hipLaunchKernelGGL((attn_kernel<256, 1>), grid, block, 0, stream, a); break;
     case 512: hipLaunchKernelGGL((attn_kernel<512, 0>), grid, block, 0, stream, a); break;
-    default: return upk_fail(ctx, UPK_ESHAPE, "attention: head dim %d not in {32,64,128,512}", d);
+    default: return upk_fail(ctx, UPK_ESHAPE, "attention: head dim %d not in {32,64,128,256,512}", d);
   }
   return upk_check_launch(ctx, "attention");
 }

@@ -17,6 +17,7 @@ namespace {
 
 constexpr int GN_MAX_CHUNKS = 64;
 constexpr int GN_GROUPS_MAX = 32;
+constexpr int GN_PREF = 4;  // x vectors prefetched per thread in gn_apply
 
 struct GnArgs {
   const f16* x1;
@@ -73,13 +74,24 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a) {
     }
   }
   __syncthreads();
-  // 64 threads: (group, sum|sumsq); a group may straddle vectors and the concat seam.
-  if (tid < a.groups * 2) {
-    const int g = tid >> 1, which = tid & 1;
+  // fold (row slot, channel) sums into groups: 4 threads per (group, sum|sumsq), each a fixed
+  // quarter of the (slot, channel) pairs, combined in a fixed order -> bitwise reproducible.
+  // A group may straddle 16-byte vectors and the concat seam, hence the per-channel walk.
+  {
+    const int q = tid >> 2, sub = tid & 3;
     float t = 0.f;
-    for (int rr = 0; rr < rpi; ++rr)
-      for (int ch = g * a.cpg; ch < (g + 1) * a.cpg; ++ch) t += sc[which][rr * C + ch];
-    a.ws[((long)(b * a.nchunks + chunk) * a.groups) * 2 + tid] = t;
+    if (q < a.groups * 2) {
+      const int g = q >> 1, which = q & 1;
+      const int n = rpi * a.cpg;
+      for (int e = sub; e < n; e += 4) {
+        const int rr = e / a.cpg;
+        const int ch = g * a.cpg + (e - rr * a.cpg);
+        t += sc[which][rr * C + ch];
+      }
+    }
+    const float t1 = t + __shfl_xor(t, 1);
+    const float t2 = t1 + __shfl_xor(t1, 2);
+    if (q < a.groups * 2 && sub == 0) a.ws[((long)(b * a.nchunks + chunk) * a.groups) * 2 + q] = t2;
   }
 }
 
@@ -89,6 +101,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a, int rows_
   const int C = a.c1 + a.c2;
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
+  // issue this thread's first x vectors NOW: their latency overlaps the statistics /
+  // table work below instead of forming a third dependent memory round trip
+  const int vpr = C >> 3;
+  const int p0 = blockIdx.x * rows_per_block;
+  const int p1 = min(a.hw, p0 + rows_per_block);
+  const int nvec = (p1 - p0) * vpr;
+  f16x8 pre[GN_PREF];
+#pragma unroll
+  for (int k = 0; k < GN_PREF; ++k) {
+    const int i = tid + k * 256;
+    if (i < nvec) {
+      const int pr = i / vpr;
+      pre[k] = gn_load(a, (long)b * a.hw + p0 + pr, i - pr * vpr);
+    }
+  }
   // fixed-order (bitwise reproducible) reduction of the chunk partials, 4 threads per
   // (group, sum|sumsq) so that the <= 64 loads per quantity are issued in parallel.
   {
@@ -122,15 +149,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a, int rows_
     shift[ch] = a.beta[ch] - smean[g] * sc;
   }
   __syncthreads();
-  const int vpr = C >> 3;
-  const int p0 = blockIdx.x * rows_per_block;
-  const int p1 = min(a.hw, p0 + rows_per_block);
-  const int nvec = (p1 - p0) * vpr;
-  for (int i = tid; i < nvec; i += 256) {
+  auto emit = [&](int i, const f16x8 xv) {
     const int pr = i / vpr;
     const int v = i - pr * vpr;
     const long pix = (long)b * a.hw + p0 + pr;
-    const f16x8 xv = gn_load(a, pix, v);
     const f32x4 sc0 = *(const f32x4*)(scale + v * 8), sc1 = *(const f32x4*)(scale + v * 8 + 4);
     const f32x4 sh0 = *(const f32x4*)(shift + v * 8), sh1 = *(const f32x4*)(shift + v * 8 + 4);
     f16x8 yv;
@@ -141,6 +163,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a, int rows_
       yv[j] = (f16)f;
     }
     *(f16x8*)(a.y + pix * a.ldy + v * 8) = yv;
+  };
+#pragma unroll
+  for (int k = 0; k < GN_PREF; ++k) {  // static register indices (no scratch)
+    const int i = tid + k * 256;
+    if (i < nvec) emit(i, pre[k]);
+  }
+  for (int i = tid + GN_PREF * 256; i < nvec; i += 256) {
+    const int pr = i / vpr;
+    emit(i, gn_load(a, (long)b * a.hw + p0 + pr, i - pr * vpr));
   }
 }
 
