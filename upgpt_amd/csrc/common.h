@@ -29,6 +29,7 @@ struct upk_ctx {
   char err[512];
   void* ws;
   size_t ws_bytes;
+  void* zero_page;  // >= 256 B of zeros in HBM (padding source for direct-to-LDS loads)
   int cfg_override;
   int splitk_override;
   // profiling

@@ -32,6 +32,7 @@ struct IgemmArgs {
   const f16* x2;
   int c1, c2, ld1, ld2;
   const f16* w;
+  const f16* zero;  // zero page (device)
   int npad;
   const float* bias;
   const f16* res;
@@ -402,6 +403,243 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Wave-specialised variant: waves 0..3 = MFMA consumers (same WM x WN tile decomposition as
+// igemm_kernel), waves 4..7 = loaders that stream the A (im2col) and B (weight) tiles global
+// -> LDS with direct-to-LDS DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write phase).
+// LDS is a ring of NBUF stage slots; the loaders run D = NBUF-1 stages ahead and wait with a
+// COUNTED vmcnt; one raw s_barrier per stage is the only synchronisation.  The consumers'
+// instruction stream is ds_read + MFMA only, so load issue / latency / LDS fill overlap the
+// matrix work inside ONE workgroup — what the UNet's 64..512-workgroup launches cannot get
+// from co-resident workgroups.  LDS-DMA writes lane-linear (base + lane*16 B), so the XOR
+// swizzle is applied to the SOURCE chunk a lane fetches; padding / out-of-range rows fetch
+// from a zero page.
+template <int P>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+}
+
+template <int MI, int NI, int WM, int WN, int KS, int NBUF>
+__global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
+  static_assert(WM * WN == 4, "4 consumer waves");
+  constexpr int BM = MI * 16 * WM;
+  constexpr int BN = NI * 16 * WN;
+  constexpr int AG = BM / 16, BG = BN / 16;          // 16-row groups (1 KiB = one wave DMA)
+  constexpr int AGW = (AG + 3) / 4, BGW = (BG + 3) / 4;  // groups per loader wave
+  constexpr int P = KS * (AGW + BGW);                 // DMAs per loader wave per stage
+  constexpr int D = NBUF - 1;                         // prefetch distance in stages
+  static_assert(D * P <= 63, "vmcnt range");
+  constexpr int ROWS = BM + BN;
+  constexpr int STAGE = KS * ROWS * 32;  // halfs per ring slot
+  constexpr int DUMP = 512;              // 1 KiB dump row group for balance DMAs
+
+  __shared__ __attribute__((aligned(16))) f16 smem[NBUF * STAGE + DUMP];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = blockIdx.x;
+  const int tn = tile / a.tiles_m;
+  const int tm = tile - tn * a.tiles_m;
+  const int m0 = tm * BM;
+  const int n0 = tn * BN;
+  const int kc0 = blockIdx.z * a.chunks_per_split;
+  const int kc1 = min(a.nchunks, kc0 + a.chunks_per_split);
+  const int nstages = (kc1 - kc0 + KS - 1) / KS;
+
+  if (wave >= 4) {
+    // ================================ loader ================================
+    const int lw = wave - 4;
+    const int r16 = lane >> 2;                                  // row inside a 16-row group
+    const int chd = (lane & 3) ^ ((-(lane >> 4)) & 3);          // source chunk of this lane (swizzle)
+    const f16* zsrc = a.zero + (lane & 3) * 8;
+    // A rows of this lane (one per owned group)
+    int a_oy[AGW], a_ox[AGW], a_b[AGW];
+    bool a_ok[AGW];
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < AGW; ++i) {
+      const int rg = lw + 4 * i;
+      const int m = m0 + rg * 16 + r16;
+      a_ok[i] = (rg < AG) && (m < a.M);
+      const int mm = a_ok[i] ? m : 0;
+      const int b = mm / HoWo;
+      const int p = mm - b * HoWo;
+      const int oy = p / a.Wo;
+      a_b[i] = b;
+      a_oy[i] = oy * a.stride - a.pad_lo;
+      a_ox[i] = (p - oy * a.Wo) * a.stride - a.pad_lo;
+    }
+    const int ctot = a.c1 + a.c2;
+    int cur_kc = kc0, cur_c0, cur_ky, cur_kx;
+    {
+      const int tap = kc0 / a.cpt;
+      cur_c0 = (kc0 - tap * a.cpt) * 32;
+      cur_ky = tap / a.ks;
+      cur_kx = tap - cur_ky * a.ks;
+    }
+    const f16* ap1[AGW];
+    const f16* ap2[AGW];
+    bool tap_ok[AGW];
+    auto set_tap = [&](int ky, int kx) {
+#pragma unroll
+      for (int i = 0; i < AGW; ++i) {
+        int iy = a_oy[i] + ky;
+        int ix = a_ox[i] + kx;
+        tap_ok[i] = a_ok[i] && iy >= 0 && iy < a.HL && ix >= 0 && ix < a.WL;
+        if (a.ups) {
+          iy >>= 1;
+          ix >>= 1;
+        }
+        const long pix = tap_ok[i] ? ((long)a_b[i] * a.HS + iy) * a.WS + ix : 0;
+        ap1[i] = a.x1 + pix * a.ld1 + chd * 8;
+        ap2[i] = a.x2 ? a.x2 + pix * a.ld2 + chd * 8 - a.c1 : a.x1;
+      }
+    };
+    set_tap(cur_ky, cur_kx);
+    // B rows of this lane
+    const f16* bp[BGW];
+    bool b_ok[BGW];
+#pragma unroll
+    for (int i = 0; i < BGW; ++i) {
+      const int rg = lw + 4 * i;
+      const int row = rg * 16 + r16;
+      b_ok[i] = (rg < BG) && (n0 + row < a.npad);
+      bp[i] = a.w + ((long)kc0 * a.npad + n0 + row) * 32 + chd * 8;
+    }
+    const long wstep = (long)a.npad * 32;
+
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    // issues the P DMAs of the next stage into ring slot `slot`
+    auto issue_stage = [&](int slot) {
+      f16* base = smem + slot * STAGE;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const bool live = cur_kc < kc1;
+        const bool second = cur_c0 >= a.c1;
+#pragma unroll
+        for (int i = 0; i < AGW; ++i) {
+          const int rg = lw + 4 * i;  // wave-uniform
+          const f16* src = (live && tap_ok[i]) ? ((second ? ap2[i] : ap1[i]) + cur_c0) : zsrc;
+          f16* dst = (rg < AG) ? base + (s * ROWS + rg * 16) * 32 : smem + NBUF * STAGE;
+          __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)dst, 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BGW; ++i) {
+          const int rg = lw + 4 * i;
+          const f16* src = (live && b_ok[i]) ? bp[i] : zsrc;
+          f16* dst = (rg < BG) ? base + (s * ROWS + BM + rg * 16) * 32 : smem + NBUF * STAGE;
+          __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)dst, 16, 0, 0);
+          bp[i] += wstep;
+        }
+        ++cur_kc;
+        cur_c0 += 32;
+        if (cur_c0 == ctot) {
+          cur_c0 = 0;
+          if (++cur_kx == a.ks) {
+            cur_kx = 0;
+            ++cur_ky;
+          }
+          if (cur_kc < kc1) set_tap(cur_ky, cur_kx);
+        }
+      }
+    };
+    // waits until at most `r - 1` whole stages are still in flight (r = stages outstanding)
+    auto wait_oldest = [&](int r) {
+      if (D >= 3 && r >= 3) wait_vmcnt<2 * P>();
+      else if (r == 2) wait_vmcnt<P>();
+      else wait_vmcnt<0>();
+    };
+    int issued = 0;
+    for (; issued < D && issued < nstages; ++issued) issue_stage(issued % NBUF);
+    wait_oldest(issued);  // stage 0 landed
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < nstages; ++t) {
+      // slot (t + D) % NBUF held stage t - 1: its readers passed the barrier that ended iteration t-1
+      if (issued < nstages) {
+        issue_stage(issued % NBUF);
+        ++issued;
+      }
+      const int outstanding = issued - (t + 1);  // stages t+1 .. issued-1
+      if (outstanding > 0) wait_oldest(outstanding);
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
+
+  // ================================ consumers ================================
+  const int wm = wave / WN;
+  const int wn = wave - wm * WN;
+  const int lg = lane >> 4;
+  const int lc = lane & 15;
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int frag_off = lc * 32 + lds_swz(lc, lg) * 8;
+  const int a_base = wm * (MI * 16) * 32 + frag_off;
+  const int b_base = (BM + wn * (NI * 16)) * 32 + frag_off;
+
+  __builtin_amdgcn_s_barrier();  // stage 0 is in LDS
+  for (int t = 0; t < nstages; ++t) {
+    const f16* slot = smem + (t % NBUF) * STAGE;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const f16* tA = slot + s * ROWS * 32 + a_base;
+      const f16* tB = slot + s * ROWS * 32 + b_base;
+      f16x8 fa[MI], fb[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = *(const f16x8*)(tA + i * 512);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) fb[j] = *(const f16x8*)(tB + j * 512);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // our LDS reads are done before the slot is reused
+    __builtin_amdgcn_s_barrier();
+  }
+
+  const int mw = m0 + wm * (MI * 16);
+  const int nw = n0 + wn * (NI * 16);
+  if (a.partial) {
+    float* slab = a.partial + (long)blockIdx.z * a.M * a.npad;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = mw + i * 16 + lc;
+      if (m >= a.M) continue;
+      const unsigned roff = (unsigned)m * (unsigned)a.npad;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = nw + j * 16 + lg * 4;
+        if (n < a.npad) *(f32x4*)(slab + roff + n) = acc[i][j];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const RowCtx rc = Epi::row(a, mw + i * 16 + lc);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = nw + j * 16 + lg * 4;
+      if (n >= a.npad) continue;
+      if (a.flags & UPK_F_GEGLU) {
+        if constexpr (NI % 4 == 0) {
+          if ((j & 2) == 0) Epi::store(a, rc, n, acc[i][j], acc[i][j + 2 < NI ? j + 2 : j]);
+        }
+      } else {
+        Epi::store(a, rc, n, acc[i][j], acc[i][j]);
+      }
+    }
+  }
+}
+
 // Split-K second pass: sums the slabs in fixed order (deterministic) and runs the epilogue.
 __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmArgs a, int splitk) {
   const int nq = a.npad >> 2;
@@ -431,10 +669,13 @@ struct CfgInfo {
   int mi, ni, wm, wn, ks;
   const char* name;
   void (*fn)(const IgemmArgs);
+  int nbuf;  // 0: classic register-staged kernel; > 0: wave-specialised DMA kernel (512 threads)
 };
 
 #define CFG(MI, NI, WM, WN, KS) \
-  {MI, NI, WM, WN, KS, #MI "x" #NI "x" #WM "x" #WN "k" #KS, igemm_kernel<MI, NI, WM, WN, KS>}
+  {MI, NI, WM, WN, KS, #MI "x" #NI "x" #WM "x" #WN "k" #KS, igemm_kernel<MI, NI, WM, WN, KS>, 0}
+#define CFGW(MI, NI, WM, WN, KS, NB) \
+  {MI, NI, WM, WN, KS, #MI "x" #NI "x" #WM "x" #WN "k" #KS "w" #NB, igemm_ws_kernel<MI, NI, WM, WN, KS, NB>, NB}
 // (MI, NI, WM, WN, KS): block tile = (MI*16*WM) x (NI*16*WN), WM*WN waves, KS K-chunks/stage.
 const CfgInfo kCfgs[] = {
     CFG(4, 4, 2, 2, 1), CFG(4, 4, 2, 2, 2),  // 128x128
@@ -453,6 +694,11 @@ const CfgInfo kCfgs[] = {
     CFG(1, 2, 4, 1, 1), CFG(1, 2, 4, 1, 4), CFG(1, 2, 4, 1, 8),  // 64x32
     CFG(1, 4, 1, 4, 1), CFG(1, 4, 1, 4, 2),  //  16x256  (tiny M: emb / context projections)
     CFG(1, 2, 2, 2, 1), CFG(1, 2, 2, 2, 4), CFG(1, 2, 2, 2, 8),  // 32x64
+    // wave-specialised (4 loader + 4 MFMA waves, LDS-DMA ring of 3 slots)
+    CFGW(4, 4, 2, 2, 2, 3), CFGW(2, 4, 2, 2, 2, 3), CFGW(4, 2, 2, 2, 2, 3), CFGW(2, 2, 2, 2, 4, 3),
+    CFGW(2, 4, 4, 1, 2, 3), CFGW(1, 4, 4, 1, 4, 3),
+    CFGW(4, 7, 2, 2, 2, 3), CFGW(2, 7, 2, 2, 2, 3), CFGW(1, 7, 2, 2, 2, 3),
+    CFGW(2, 7, 4, 1, 2, 3), CFGW(1, 7, 4, 1, 4, 3), CFGW(2, 2, 2, 2, 2, 3), CFGW(1, 7, 4, 1, 2, 3),
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -474,7 +720,7 @@ double estimate(const CfgInfo& c, int M, int npad, int nchunks, int splitk, int 
   const double gl = (BM + BN) * 64.0 / 40.0;  // bytes / (B/clk/CU sustained from L2)
   const double work = fmax(fmax(mfma, lds), gl) * c.ks;
   // workgroups resident per CU (LDS + registers), they overlap each other's stalls
-  const int lds_bytes = 2 * c.ks * (BM + BN) * 64;
+  const int lds_bytes = (c.nbuf ? c.nbuf : 2) * c.ks * (BM + BN) * 64;
   int occ = 160 * 1024 / lds_bytes;
   const int nt = waves * 64;
   const int stage_regs = c.ks * (cdiv(BM * 4, nt) + cdiv(BN * 4, nt)) * 4;
@@ -488,7 +734,7 @@ double estimate(const CfgInfo& c, int M, int npad, int nchunks, int splitk, int 
   const double rounds = ceil(wgs / slots);
   const long resident = wgs < (long)slots ? (wgs + cus - 1) / cus : occ;  // WGs actually sharing a CU
   // one stage: its own work (shared with co-resident WGs) or the exposed load latency
-  const double latency = 1400.0;
+  const double latency = c.nbuf ? 500.0 : 1400.0;  // the DMA ring hides most of the load latency
   const double per_stage = fmax(work * (double)resident, latency) + 150.0;
   double t = rounds * (stages * per_stage + 2500.0);
   if (splitk > 1) t += 6000.0 + (double)M * npad * splitk * 8.0 / (cus * 8.0);
@@ -534,6 +780,7 @@ extern "C" int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_str
   a.ld1 = d->ld1;
   a.ld2 = d->ld2;
   a.w = (const f16*)d->w_packed;
+  a.zero = (const f16*)ctx->zero_page;
   a.npad = d->n_pad;
   a.bias = d->bias;
   a.res = (const f16*)d->residual;
@@ -615,7 +862,7 @@ extern "C" int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_str
 
   upk_prof_scope prof(ctx, UPK_CLS_IGEMM, stream);
   dim3 grid(a.tiles_m * a.tiles_n, 1, zdim);
-  hipLaunchKernelGGL(c.fn, grid, dim3(c.wm * c.wn * 64), 0, stream, a);
+  hipLaunchKernelGGL(c.fn, grid, dim3(c.nbuf ? 512 : c.wm * c.wn * 64), 0, stream, a);
   int rc = upk_check_launch(ctx, "igemm");
   if (rc) return rc;
   if (zdim > 1) {

@@ -21,6 +21,17 @@ extern "C" int upk_create(upk_ctx** out, int device) {
   c->err[0] = 0;
   c->ws = nullptr;
   c->ws_bytes = 0;
+  c->zero_page = nullptr;
+  {
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    (void)hipSetDevice(device);
+    if (hipMalloc(&c->zero_page, 4096) != hipSuccess || hipMemset(c->zero_page, 0, 4096) != hipSuccess) {
+      delete c;
+      return UPK_EHIP;
+    }
+    (void)hipSetDevice(cur);
+  }
   c->cfg_override = -1;
   c->splitk_override = 0;
   c->prof_on = 0;
@@ -42,6 +53,7 @@ extern "C" int upk_destroy(upk_ctx* ctx) {
     (void)hipEventDestroy(r.e0);
     (void)hipEventDestroy(r.e1);
   }
+  if (ctx->zero_page) (void)hipFree(ctx->zero_page);
   delete ctx;
   return UPK_OK;
 }
