@@ -19,6 +19,8 @@ from upgpt_amd.engine import TUNE_CACHE  # noqa: E402
 
 out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/tuned_gfx950.json"
 kinds = sys.argv[2].split(",") if len(sys.argv) > 2 else ["bbox"]
+if os.environ.get("UPGPT_TUNE_KEEP", "0") != "1":
+    TUNE_CACHE.d = {}  # re-measure everything (kernel set may have changed)
 
 
 def summarize(name, emitter):
