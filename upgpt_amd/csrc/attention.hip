@@ -28,32 +28,42 @@ struct AttnArgs {
   float scale_log2;  // scale * log2(e)
 };
 
-// One K/V tile of NS*16 keys for the 16 queries of this wave (NS = 4 in the main loop, 2 for
-// the tail).  Scores stay unscaled; softmax uses exp2(s*c - m*c) with c = scale*log2(e) folded
-// into one FMA per score.  V^T fragments are requested before the softmax arithmetic so
-// their latency hides under it.
-template <int D, int QREG, int NS>
-__device__ __forceinline__ void attn_tile(const AttnArgs& a, const f16* qrow, bool q_ok, const f16x8* qf,
-                                          const f16* kbase, const f16* vbase, int kb, int g, int c,
-                                          f32x4* o, float& mrun, float& lrun) {
+// One K/V tile of NS*16 keys for the QT*16 queries of this wave (NS = 4 in the main loop, 2
+// for the tail).  Every K / V^T fragment is loaded ONCE and used for all QT query groups (the
+// level-1 self-attention is bound by K/V re-reads through L1/L2, not by MFMA).  Scores stay
+// unscaled; softmax uses exp2(s*c - m*c) with c = scale*log2(e) folded into one FMA per
+// score.  V^T fragments are requested before the softmax arithmetic so their latency hides
+// under it.
+template <int D, int QREG, int NS, int QT>
+__device__ __forceinline__ void attn_tile(const AttnArgs& a, const f16* const* qrow, const bool* q_ok,
+                                          const f16x8 (*qf)[QREG ? D / 32 : 1], const f16* kbase,
+                                          const f16* vbase, int kb, int g, int c, f32x4 (*o)[D / 16], float* mrun,
+                                          float* lrun) {
   constexpr int KD = D / 32;
   constexpr int DT = D / 16;
   constexpr int NC = NS / 2;  // 32-key chunks for the PV MFMAs
   const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  f32x4 s[NS];
+  f32x4 s[QT][NS];
   const f16* kp[NS];
 #pragma unroll
   for (int t = 0; t < NS; ++t) {
-    s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int key = kb + 16 * t + c;
     kp[t] = kbase + (long)(key < a.nkv ? key : 0) * a.ldk;
+#pragma unroll
+    for (int u = 0; u < QT; ++u) s[u][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 #pragma unroll
   for (int kd = 0; kd < KD; ++kd) {
-    const f16x8 qv = QREG ? qf[kd] : (q_ok ? *(const f16x8*)(qrow + kd * 32) : zero8);
+    f16x8 qv[QT];
 #pragma unroll
-    for (int t = 0; t < NS; ++t)
-      s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const f16x8*)(kp[t] + kd * 32), qv, s[t], 0, 0, 0);
+    for (int u = 0; u < QT; ++u)
+      qv[u] = QREG ? qf[u][kd] : (q_ok[u] ? *(const f16x8*)(qrow[u] + kd * 32) : zero8);
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+      const f16x8 kf = *(const f16x8*)(kp[t] + kd * 32);
+#pragma unroll
+      for (int u = 0; u < QT; ++u) s[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qv[u], s[u][t], 0, 0, 0);
+    }
   }
   // V^T operand fragments (only when they fit in registers next to the accumulators)
   constexpr bool VPRE = (D <= 128);
@@ -68,37 +78,42 @@ __device__ __forceinline__ void attn_tile(const AttnArgs& a, const f16* qrow, bo
         vpre[(i * NC + j) * 2 + 1] = *(const f16x4*)(vr + 16);
       }
   }
-  // lane (g, c) holds keys kb + 16t + 4g + r of query c
-  float mx = -INFINITY;
-  if (kb + NS * 16 > a.nkv) {  // tail tile: mask keys beyond n_kv (wave-uniform branch)
+  const float cs = a.scale_log2;
+  f16x8 pf[QT][NC];
+  const bool tail = kb + NS * 16 > a.nkv;  // wave-uniform
+#pragma unroll
+  for (int u = 0; u < QT; ++u) {
+    // lane (g, c) holds keys kb + 16t + 4g + r of query c of group u
+    if (tail) {
+#pragma unroll
+      for (int t = 0; t < NS; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (kb + 16 * t + 4 * g + r >= a.nkv) s[u][t][r] = -INFINITY;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NS; ++t)
+      mx = fmaxf(mx, fmaxf(fmaxf(s[u][t][0], s[u][t][1]), fmaxf(s[u][t][2], s[u][t][3])));
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mnew = fmaxf(mrun[u], mx);  // finite: every tile has >= 1 valid key
+    const float alpha = exp2f((mrun[u] - mnew) * cs);
+    mrun[u] = mnew;
+    const float mc = -mnew * cs;
+    float ps = 0.f;
 #pragma unroll
     for (int t = 0; t < NS; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (kb + 16 * t + 4 * g + r >= a.nkv) s[t][r] = -INFINITY;
+      for (int r = 0; r < 4; ++r) {
+        const float p = exp2f(fmaf(s[u][t][r], cs, mc));
+        ps += p;
+        pf[u][t >> 1][(t & 1) * 4 + r] = (f16)p;
+      }
+    lrun[u] = lrun[u] * alpha + ps;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[u][i] *= alpha;
   }
-#pragma unroll
-  for (int t = 0; t < NS; ++t) mx = fmaxf(mx, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
-  mx = fmaxf(mx, __shfl_xor(mx, 16));
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
-  const float cs = a.scale_log2;
-  const float mnew = fmaxf(mrun, mx);  // finite: every tile has >= 1 valid key
-  const float alpha = exp2f((mrun - mnew) * cs);
-  mrun = mnew;
-  const float mc = -mnew * cs;
-  f16x8 pf[NC];
-  float ps = 0.f;
-#pragma unroll
-  for (int t = 0; t < NS; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float p = exp2f(fmaf(s[t][r], cs, mc));
-      ps += p;
-      pf[t >> 1][(t & 1) * 4 + r] = (f16)p;
-    }
-  lrun = lrun * alpha + ps;
-#pragma unroll
-  for (int i = 0; i < DT; ++i) o[i] *= alpha;
 #pragma unroll
   for (int i = 0; i < DT; ++i)
 #pragma unroll
@@ -113,11 +128,13 @@ __device__ __forceinline__ void attn_tile(const AttnArgs& a, const f16* qrow, bo
         vb = *(const f16x4*)(vr + 16);
       }
       const f16x8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
-      o[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[j], o[i], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < QT; ++u) o[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[u][j], o[u][i], 0, 0, 0);
     }
 }
 
-template <int D, int QREG>
+// grid.x = ceil(n_q / (64*QT)), grid.y = B*heads; 4 waves, each QT groups of 16 query rows.
+template <int D, int QREG, int QT>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   constexpr int KD = D / 32;  // k-steps of Q K^T
   constexpr int DT = D / 16;  // output sub-tiles
@@ -127,42 +144,54 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   const int bh = blockIdx.y;
   const int b = bh / a.heads;
   const int h = bh - b * a.heads;
-  const int q0 = (blockIdx.x * 4 + wave) * 16;
+  const int q0 = (blockIdx.x * 4 + wave) * 16 * QT;
   if (q0 >= a.nq) return;
-  const int qi = q0 + c;
-  const bool q_ok = qi < a.nq;
-  const f16* qrow = a.q + b * a.qbs + (long)(q_ok ? qi : 0) * a.ldq + h * D + g * 8;
   const f16* kbase = a.k + b * a.kbs + h * D + g * 8;
   const f16* vbase = a.vt + ((long)(b * a.heads + h) * D + c) * a.vt_ld + g * 4;
   const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-  f16x8 qf[QREG ? KD : 1];
-  if (QREG) {
+  const f16* qrow[QT];
+  bool q_ok[QT];
+  f16x8 qf[QT][QREG ? KD : 1];
+  f32x4 o[QT][DT];
+  float mrun[QT], lrun[QT];
 #pragma unroll
-    for (int kd = 0; kd < KD; ++kd) qf[kd] = q_ok ? *(const f16x8*)(qrow + kd * 32) : zero8;
+  for (int u = 0; u < QT; ++u) {
+    const int qi = q0 + u * 16 + c;
+    q_ok[u] = qi < a.nq;
+    qrow[u] = a.q + b * a.qbs + (long)(q_ok[u] ? qi : 0) * a.ldq + h * D + g * 8;
+    if (QREG) {
+#pragma unroll
+      for (int kd = 0; kd < KD; ++kd) qf[u][kd] = q_ok[u] ? *(const f16x8*)(qrow[u] + kd * 32) : zero8;
+    }
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[u][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mrun[u] = -INFINITY;
+    lrun[u] = 0.f;
   }
-  f32x4 o[DT];
-#pragma unroll
-  for (int i = 0; i < DT; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float mrun = -INFINITY, lrun = 0.f;
 
   int kb = 0;
   if (D <= 128) {  // 64-key tiles while they are full; the 32-key form handles the rest
-    for (; kb + 64 <= a.nkv; kb += 64) attn_tile<D, QREG, 4>(a, qrow, q_ok, qf, kbase, vbase, kb, g, c, o, mrun, lrun);
+    for (; kb + 64 <= a.nkv; kb += 64)
+      attn_tile<D, QREG, 4, QT>(a, qrow, q_ok, qf, kbase, vbase, kb, g, c, o, mrun, lrun);
   }
-  for (; kb < a.nkv; kb += 32) attn_tile<D, QREG, 2>(a, qrow, q_ok, qf, kbase, vbase, kb, g, c, o, mrun, lrun);
+  for (; kb < a.nkv; kb += 32) attn_tile<D, QREG, 2, QT>(a, qrow, q_ok, qf, kbase, vbase, kb, g, c, o, mrun, lrun);
 
-  lrun += __shfl_xor(lrun, 16);
-  lrun += __shfl_xor(lrun, 32);
-  const float inv = 1.0f / lrun;
-  if (!q_ok) return;
-  f16* orow = a.o + b * a.obs + (long)qi * a.ldo + h * D + g * 4;
 #pragma unroll
-  for (int i = 0; i < DT; ++i) {
-    f16x4 ov;
+  for (int u = 0; u < QT; ++u) {
+    float l = lrun[u];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    if (!q_ok[u]) continue;
+    f16* orow = a.o + b * a.obs + (long)(q0 + u * 16 + c) * a.ldo + h * D + g * 4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ov[r] = (f16)(o[i][r] * inv);
-    *(f16x4*)(orow + i * 16) = ov;
+    for (int i = 0; i < DT; ++i) {
+      f16x4 ov;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ov[r] = (f16)(o[u][i][r] * inv);
+      *(f16x4*)(orow + i * 16) = ov;
+    }
   }
 }
 
@@ -194,15 +223,23 @@ extern "C" int upk_attention_f16(upk_ctx* ctx, const void* q, int ldq, long long
   a.nq = n_q;
   a.nkv = n_kv;
   a.scale_log2 = scale * 1.4426950408889634f;
-  dim3 grid((n_q + 63) / 64, batch * heads), block(256);
+  // two 16-query groups per wave when there are enough queries to keep every CU busy
+  const int qt = (d <= 128 && (long)((n_q + 127) / 128) * batch * heads >= 2L * ctx->num_cus) ? 2 : 1;
+  dim3 grid((n_q + 64 * qt - 1) / (64 * qt), batch * heads), block(256);
   upk_prof_scope prof(ctx, UPK_CLS_ATTN, stream);
+#define UPK_ATTN(D_, QR_)                                                                         \
+  if (qt == 2)                                                                                    \
+    hipLaunchKernelGGL((attn_kernel<D_, QR_, (D_ <= 128 ? 2 : 1)>), grid, block, 0, stream, a);  \
+  else                                                                                            \
+    hipLaunchKernelGGL((attn_kernel<D_, QR_, 1>), grid, block, 0, stream, a);
   switch (d) {
-    case 32: hipLaunchKernelGGL((attn_kernel<32, 1>), grid, block, 0, stream, a); break;
-    case 64: hipLaunchKernelGGL((attn_kernel<64, 1>), grid, block, 0, stream, a); break;
-    case 128: hipLaunchKernelGGL((attn_kernel<128, 1>), grid, block, 0, stream, a); break;
-    case 256: hipLaunchKernelGGL((attn_kernel<256, 1>), grid, block, 0, stream, a); break;
-    case 512: hipLaunchKernelGGL((attn_kernel<512, 0>), grid, block, 0, stream, a); break;
+    case 32: UPK_ATTN(32, 1) break;
+    case 64: UPK_ATTN(64, 1) break;
+    case 128: UPK_ATTN(128, 1) break;
+    case 256: hipLaunchKernelGGL((attn_kernel<256, 1, 1>), grid, block, 0, stream, a); break;
+    case 512: hipLaunchKernelGGL((attn_kernel<512, 0, 1>), grid, block, 0, stream, a); break;
     default: return upk_fail(ctx, UPK_ESHAPE, "attention: head dim %d not in {32,64,128,256,512}", d);
   }
+#undef UPK_ATTN
   return upk_check_launch(ctx, "attention");
 }
