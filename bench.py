@@ -69,27 +69,50 @@ def timed(fn, n, dev):
     return time.perf_counter() - t0, out
 
 
-def kernel_class_profile(model, wl, reps=3):
-    """Per-kernel-class durations measured live with HIP events on the launch stream
-    (upk_prof_*), over `reps` eager UNet forwards of the bench workload."""
+def kernel_class_profile(model, wl, reps=10):
+    """Per-kernel-class GPU time of one UNet forward, measured live under the SAME conditions
+    as the timed region (HIP-graph replay): the forward's launch list is captured once in full
+    and once without the class, both replayed `reps` times between HIP events recorded on the
+    launch stream; the difference is the class time.  (Bracketing single launches with events
+    in eager mode over-reads 10-us kernels by 20-30 %: eager launching is host-bound.)"""
+    import ctypes as C
     from upgpt_amd._lib import get_context
     ctx = get_context(0)
     unet = model.model.diffusion_model
     B, (H, W) = wl.B, wl.hw
     with model.ema_scope():
         plan = unet.plan(B, H, W, 87, wl.S, "sampler")
-        plan.step.zero_()
-        plan.body.run()  # warm
+        body = plan.body
+        s = torch.cuda.Stream()
+
+        def timed(skip):
+            with torch.cuda.stream(s):
+                sp = s.cuda_stream
+                ctx._chk(ctx.lib.upk_graph_begin(ctx.h, sp))
+                body.run(sp, skip=skip)
+                g = C.c_void_p()
+                ctx._chk(ctx.lib.upk_graph_end(ctx.h, sp, C.byref(g)))
+                ctx._chk(ctx.lib.upk_graph_launch(ctx.h, g, sp))
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(s)
+                for _ in range(reps):
+                    ctx._chk(ctx.lib.upk_graph_launch(ctx.h, g, sp))
+                e1.record(s)
+                s.synchronize()
+                ctx.graph_destroy(g)
+                return e0.elapsed_time(e1) / reps
+
         torch.cuda.synchronize()
-        ctx.prof_enable(True)
-        for _ in range(reps):
-            plan.step.zero_()
-            plan.body.run()
+        full = timed(())
+        names = {"igemm": ("igemm_k1", "igemm_k3"), "attention": ("attention",), "groupnorm": ("groupnorm",),
+                 "layernorm": ("layernorm",)}
+        out = {}
+        for k, classes in names.items():
+            n = sum(1 for c in body.cls if c in classes)
+            out[k] = {"ms_per_fwd": full - timed(classes), "launches_per_fwd": n}
+        plan.prep.run()  # the ablated replays left garbage in the activations
         torch.cuda.synchronize()
-        res = ctx.prof_collect()
-        ctx.prof_enable(False)
-    out = {k: {"ms_per_fwd": v[0] / reps, "launches_per_fwd": v[1] / reps} for k, v in res.items()}
-    return out, plan.body.igemm_flops, plan.body.attn_flops, plan.body.n_launch
+    return out, body.igemm_flops, body.attn_flops, body.n_launch, full
 
 
 def unet_forward_ms(model, wl, reps=20):
@@ -200,17 +223,20 @@ def main():
         a = arch.UNetArch(**synth.BBOX_UNET)
         flops_fwd = a.flops(args.batch, hw[0], hw[1], 87)
         fwd_ms = unet_forward_ms(model, wl)
-        prof, ig_flops, at_flops, n_launch = kernel_class_profile(model, wl)
+        prof, ig_flops, at_flops, n_launch, body_ms = kernel_class_profile(model, wl)
         ig_ms = prof["igemm"]["ms_per_fwd"]
         achieved = ig_flops / (ig_ms * 1e-3) / 1e12
         result["roofline"] = {
-            "bound": "mfma", "kernel": "igemm_kernel<*> (implicit-GEMM conv/linear, all tile configs)",
+            "bound": "mfma",
+            "kernel": "igemm_ws_kernel<*> + igemm_kernel<*> + igemm_reduce_kernel (implicit-GEMM conv/linear, every "
+                      "tile config; 194 launches per UNet forward)",
+            "method": "graph-replay difference: (forward) - (forward without the class), HIP events on the launch stream",
             "achieved": achieved, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F16_TFLOPS,
             "traffic": None,
             "algorithmic_flops_per_fwd": ig_flops, "avg_launch_us": ig_ms * 1e3 / max(1.0, prof["igemm"]["launches_per_fwd"]),
             "launches_per_fwd": prof["igemm"]["launches_per_fwd"],
         }
-        result["unet"] = {"fwd_ms_graph": fwd_ms, "algorithmic_gflop_per_fwd": flops_fwd / 1e9,
+        result["unet"] = {"fwd_ms_graph": fwd_ms, "body_ms_graph": body_ms, "algorithmic_gflop_per_fwd": flops_fwd / 1e9,
                           "mfma_util": flops_fwd / (fwd_ms * 1e-3) / (PEAK_MFMA_F16_TFLOPS * 1e12),
                           "kernel_launches_per_fwd": n_launch, "class_ms_per_fwd": {k: v["ms_per_fwd"] for k, v in prof.items()}}
         tdec, _ = timed(lambda: model.decode_first_stage(wl.x_T), 3, dev) if world == 1 else (None, None)
