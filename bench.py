@@ -115,6 +115,18 @@ def kernel_class_profile(model, wl, reps=10):
     return out, body.igemm_flops, body.attn_flops, body.n_launch, full
 
 
+def igemm_traffic_bytes_per_launch():
+    """HBM-side bytes per igemm launch from the PMC passes of scripts/gpu_traffic.sh
+    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; rocprofv3 cannot run inside this process), or
+    None when the summary for the current kernels has not been collected."""
+    f = os.path.join(ROOT, "profiles", "r01_igemm_traffic.json")
+    try:
+        with open(f) as fh:
+            return json.load(fh)["bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def unet_forward_ms(model, wl, reps=20):
     """Graph-replayed UNet forward + DDIM update (one sampler step), ms."""
     unet = model.model.diffusion_model
@@ -232,7 +244,7 @@ def main():
                       "tile config; 194 launches per UNet forward)",
             "method": "graph-replay difference: (forward) - (forward without the class), HIP events on the launch stream",
             "achieved": achieved, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F16_TFLOPS,
-            "traffic": None,
+            "traffic": igemm_traffic_bytes_per_launch(),
             "algorithmic_flops_per_fwd": ig_flops, "avg_launch_us": ig_ms * 1e3 / max(1.0, prof["igemm"]["launches_per_fwd"]),
             "launches_per_fwd": prof["igemm"]["launches_per_fwd"],
         }
