@@ -1,2 +1,2 @@
 """ldm.models.autoencoder -> upgpt_amd.vae."""
-from upgpt_amd.vae import AutoencoderKL  # noqa: F401
+from upgpt_amd.vae import AutoencoderKL, DiagonalGaussianDistribution  # noqa: F401

@@ -72,3 +72,37 @@ def decode_first_stage(sd, dd, z, scale_factor=0.18215, prefix="first_stage_mode
     z = 1.0 / scale_factor * z
     z = _conv(sd, prefix + "post_quant_conv", z, padding=0)
     return decoder_forward(sd, dd, z, prefix + "decoder.")
+
+
+@torch.no_grad()
+def encoder_forward(sd, dd, x, prefix="first_stage_model.encoder."):
+    """model.py:434-459 (Encoder.forward, temb=None).  Downsample = pad (0,1,0,1) then
+    conv3x3 stride 2 without padding (model.py:70-76)."""
+    nres = len(dd["ch_mult"])
+    nrb = dd["num_res_blocks"]
+    attn_resolutions = list(dd.get("attn_resolutions", []))
+    curr_res = dd["resolution"]
+    h = _conv(sd, prefix + "conv_in", x)
+    for lvl in range(nres):
+        for ib in range(nrb):
+            h = resnet_block(sd, prefix + "down.%d.block.%d" % (lvl, ib), h)
+            if curr_res in attn_resolutions:
+                h = attn_block(sd, prefix + "down.%d.attn.%d" % (lvl, ib), h)
+        if lvl != nres - 1:
+            h = F.pad(h, (0, 1, 0, 1), mode="constant", value=0)
+            n = prefix + "down.%d.downsample.conv" % lvl
+            h = F.conv2d(h, sd[n + ".weight"], sd[n + ".bias"], stride=2, padding=0)
+            curr_res //= 2
+    h = resnet_block(sd, prefix + "mid.block_1", h)
+    h = attn_block(sd, prefix + "mid.attn_1", h)
+    h = resnet_block(sd, prefix + "mid.block_2", h)
+    h = F.silu(_gn(sd, prefix + "norm_out", h))
+    return _conv(sd, prefix + "conv_out", h)
+
+
+@torch.no_grad()
+def encode_moments(sd, dd, x, prefix="first_stage_model."):
+    """autoencoder.py:324-328: moments = quant_conv(encoder(x)); the posterior is
+    DiagonalGaussianDistribution(moments) (distributions.py:24-36: mean | logvar clamp [-30, 20])."""
+    h = encoder_forward(sd, dd, x, prefix + "encoder.")
+    return _conv(sd, prefix + "quant_conv", h, padding=0)

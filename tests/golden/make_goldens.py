@@ -32,7 +32,9 @@ REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, REF)          # `ldm` must resolve to the reference here
-sys.path.append(ROOT)            # upgpt_amd.synth only
+# NOTE: the repo root must NOT be on sys.path: its `ldm/` alias package (a regular package) would
+# shadow the reference's `ldm` (a namespace package without __init__.py) regardless of order.
+sys.path[:] = [p for p in sys.path if os.path.abspath(p or ".") != ROOT]
 
 torch.set_grad_enabled(False)
 
@@ -86,7 +88,10 @@ from ldm.modules.diffusionmodules.util import (make_beta_schedule, make_ddim_sam
                                                 make_ddim_timesteps, timestep_embedding)
 
 assert ref_ddim.__file__.startswith(REF)
-from upgpt_amd import synth  # noqa: E402
+import importlib.util  # noqa: E402
+_spec = importlib.util.spec_from_file_location("upgpt_synth", os.path.join(ROOT, "upgpt_amd", "synth.py"))
+synth = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(synth)  # the recipe module only (numpy / torch / zlib)
 
 ref_ddim.DDIMSampler.register_buffer = lambda self, n, a: setattr(self, n, a)
 
@@ -212,6 +217,26 @@ def gen_model_goldens(kind, out):
     print(kind, "->", out, {k: getattr(v, "shape", None) for k, v in list(g.items())[:4]})
 
 
+def gen_encode(kind, out):
+    """First-stage ENCODER goldens: posterior moments of a synthetic image,
+    plus DDIMSampler.stochastic_encode on the posterior mode."""
+    model, params = build_reference(kind)
+    f = 2 ** (len(params["first_stage_config"]["params"]["ddconfig"]["ch_mult"]) - 1)
+    g0 = torch.Generator().manual_seed(4242)
+    img = torch.rand(1, 3, 32 * f, 24 * f, generator=g0) * 2 - 1
+    post = model.encode_first_stage(img)
+    g = {"moments": post.parameters.numpy(), "img_crc": np.asarray(synth.crc_of(img), dtype=np.uint64)}
+    z = model.get_first_stage_encoding(post.mode())
+    g["z_mode_scaled"] = z.numpy()
+    sampler = ref_ddim.DDIMSampler(model)
+    sampler.make_schedule(ddim_num_steps=50, ddim_eta=0.0, verbose=False)
+    noise = torch.randn(z.shape, generator=g0)
+    g["stoch_noise_crc"] = np.asarray(synth.crc_of(noise), dtype=np.uint64)
+    g["stoch_enc_t25"] = sampler.stochastic_encode(z, torch.tensor([25]), noise=noise).numpy()
+    np.savez_compressed(out, **g)
+    print("encode", kind, "->", out, g["moments"].shape)
+
+
 def gen_schedule(out):
     g = {}
     for name, (ls, le) in {"bbox": (0.00085, 0.012), "upscale": (0.0001, 0.02)}.items():
@@ -242,9 +267,12 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    kinds = [a.only] if a.only else ["schedule", "tiny", "bbox", "upscale"]
+    kinds = [a.only] if a.only else ["schedule", "tiny", "bbox", "upscale", "encode"]
     for k in kinds:
-        if k == "schedule":
+        if k == "encode":
+            for kind in ("tiny", "bbox", "upscale"):
+                gen_encode(kind, os.path.join(HERE, "encode_%s.npz" % kind))
+        elif k == "schedule":
             gen_schedule(os.path.join(HERE, "schedule.npz"))
         else:
             gen_model_goldens(k, os.path.join(HERE, "%s.npz" % k))

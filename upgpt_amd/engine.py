@@ -642,6 +642,102 @@ class VAEDecodePlan(Emitter):
         return self.img
 
 
+# ====================================================================== VAE encoder
+class PackedVAEEncoder:
+    def __init__(self, ctx, arch: VAEArch, get):
+        pk = Packer(ctx, get)
+        self.arch = arch
+        w, v = {}, {}
+
+        def norm(name):
+            v[name] = (pk.vec("encoder." + name + ".weight"), pk.vec("encoder." + name + ".bias"))
+
+        for Lr in arch.encoder:
+            n, d = Lr.name, "encoder." + Lr.name
+            if Lr.kind in ("conv", "conv_out"):
+                w[n] = pk.pack(d, cin_packed=_rup(Lr.cin, 32))
+            elif Lr.kind == "resnet":
+                norm(n + ".norm1")
+                w[n + ".conv1"] = pk.pack(d + ".conv1")
+                norm(n + ".norm2")
+                w[n + ".conv2"] = pk.pack(d + ".conv2")
+                if Lr.cin != Lr.cout:
+                    w[n + ".nin_shortcut"] = pk.pack(d + ".nin_shortcut")
+            elif Lr.kind == "attn":
+                if Lr.ch not in (32, 64, 128, 256, 512):
+                    raise NotImplementedError("VAE AttnBlock width %d" % Lr.ch)
+                norm(n + ".norm")
+                w[n + ".qkv"] = pk.pack([d + ".q", d + ".k", d + ".v"], n_out=2 * Lr.ch)
+                w[n + ".proj_out"] = pk.pack(d + ".proj_out")
+            elif Lr.kind == "downconv":
+                w[n] = pk.pack(d)
+            elif Lr.kind == "norm_out":
+                norm(n)
+        zc2 = arch.encoder[-1].cout
+        w["quant_conv"] = pk.pack("quant_conv", cin_packed=_rup(zc2, 32))
+        self.w, self.v = w, v
+
+
+class VAEEncodePlan(Emitter):
+    """AutoencoderKL.encode (autoencoder.py:324-328): Encoder (model.py:434-459) -> quant_conv ->
+    posterior moments [B, 2*embed_dim, h, w] fp32 NCHW.  Same kernels as the decoder; the
+    stride-2 Downsample uses the asymmetric (0,1,0,1) padding mode of the implicit GEMM."""
+
+    def __init__(self, ctx, packed: PackedVAEEncoder, B, H, W):
+        super().__init__(ctx)
+        self.pk, self.arch = packed, packed.arch
+        a = self.arch
+        f = a.factor
+        assert H % f == 0 and W % f == 0, "image size must be a multiple of %d" % f
+        self.x = self.alloc(B, a.in_channels, H, W, dtype=torch.float32)
+        self.moments = self.alloc(B, 2 * a.embed_dim, H // f, W // f, dtype=torch.float32)
+        self.gn_ws = self.alloc(max(64, ctx.groupnorm_ws_bytes(B, H * W) // 4), dtype=torch.float32)
+        self.prog = Program(ctx)
+        P, W_, V_ = self.prog, packed.w, packed.v
+        xin = Act(self.alloc(B * H * W, _rup(a.in_channels, 32), zero=True), B, H, W, a.in_channels)
+        lib, hh, chk, xs = self.lib, self.hctx, self._chk, self.x
+        P.add(lambda s: chk(lib.upk_nchw_f32_to_nhwc_f16(hh, xs.data_ptr(), B, a.in_channels, H * W,
+                                                         xin.t.data_ptr(), xin.ld, 0, 0, 1.0, s)))
+        x = xin
+        for Lr in a.encoder:
+            n = Lr.name
+            if Lr.kind == "conv":
+                x = self.conv(P, x, W_[n])
+            elif Lr.kind == "resnet":
+                hN = self.groupnorm(P, x, *V_[n + ".norm1"], 1e-6, True, self.gn_ws)
+                h1 = self.conv(P, hN, W_[n + ".conv1"])
+                hN = self.groupnorm(P, h1, *V_[n + ".norm2"], 1e-6, True, self.gn_ws)
+                sk = self.conv(P, x, W_[n + ".nin_shortcut"]) if Lr.cin != Lr.cout else x
+                x = self.conv(P, hN, W_[n + ".conv2"], residual=sk)
+            elif Lr.kind == "attn":
+                c, HW = Lr.ch, x.H * x.W
+                xn = self.groupnorm(P, x, *V_[n + ".norm"], 1e-6, False, self.gn_ws)
+                qk = Act(self.alloc(x.M, 2 * c), x.B, x.H, x.W, 2 * c)
+                vt_ld = _rup(HW, 32)
+                vt = self.alloc(x.B, 1, c, vt_ld, zero=True)
+                self.conv(P, xn, W_[n + ".qkv"], out=qk,
+                          vt=dict(t=vt, heads=1, dhead=c, ld=vt_ld, tokens=HW, **{"from": 2 * c}))
+                ao = Act(self.alloc(x.M, c), x.B, x.H, x.W, c)
+                self.attention(P, qk.t, 2 * c, HW * 2 * c, qk.t[:, c:], 2 * c, HW * 2 * c, vt, vt_ld, ao.t, c, HW * c,
+                               x.B, 1, HW, HW, c, int(c) ** -0.5)
+                x = self.conv(P, ao, W_[n + ".proj_out"], residual=x)
+            elif Lr.kind == "downconv":
+                x = self.conv(P, x, W_[n], stride=2, flags=L.F_PAD_ASYM)
+            elif Lr.kind == "norm_out":
+                x = self.groupnorm(P, x, *V_[n], 1e-6, True, self.gn_ws)
+            elif Lr.kind == "conv_out":
+                x = self.conv(P, x, W_[n], out=Act(self.alloc(x.M, _rup(Lr.cout, 32), zero=True), x.B, x.H, x.W,
+                                                   Lr.cout))
+        self.conv(P, x, W_["quant_conv"], nchw_out=self.moments)
+
+    def run(self, img):
+        img = img.to(self.dev, torch.float32).contiguous()
+        assert tuple(img.shape) == tuple(self.x.shape), (img.shape, self.x.shape)
+        self.x.copy_(img)
+        self.prog.run()
+        return self.moments
+
+
 # ====================================================================== sampler step graph
 class SamplerState:
     """Device state of one DDIM run on a sampler-mode UNetPlan: latent x (fp32 NCHW),

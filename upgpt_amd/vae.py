@@ -1,7 +1,7 @@
 """AutoencoderKL — drop-in for ldm.models.autoencoder.AutoencoderKL (ctor 286-306,
-decode 330-333) with the Decoder (model.py:462-568) running on libupk.so.  The encoder's
-parameters are held (checkpoint keys first_stage_model.encoder.*) but encode() is a
-"next" row of SURVEY.md §8f and raises until it is built on the same kernels."""
+encode 324-328, decode 330-333) with the Encoder / Decoder (model.py:368-568) running on
+libupk.so: decode is on the images/sec path, encode is the first "next" row of SURVEY.md
+§8f (reconstruction output of log_images, img2img entry)."""
 import os
 
 import torch
@@ -9,6 +9,38 @@ import torch
 from .arch import VAEArch
 from .config import instantiate_from_config
 from .params import ParamTree, weights_fingerprint
+
+
+class DiagonalGaussianDistribution(object):
+    """Posterior q(z|x) from the encoder's moments (ldm/modules/distributions/distributions.py:24-65):
+    mean | logvar split along channels, logvar clamped to [-30, 20].  A handful of element-wise
+    ops on a [B, 2z, h, w] tensor once per batch — plain tensor arithmetic, not a kernel."""
+
+    def __init__(self, parameters, deterministic=False):
+        self.parameters = parameters
+        self.mean, logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(logvar, -30.0, 20.0)
+        self.deterministic = deterministic
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+        if deterministic:
+            self.var = self.std = torch.zeros_like(self.mean)
+
+    def sample(self, noise=None):
+        if noise is None:
+            noise = torch.randn(self.mean.shape, device=self.parameters.device)
+        return self.mean + self.std * noise.to(self.mean.device)
+
+    def mode(self):
+        return self.mean
+
+    def kl(self, other=None):
+        if self.deterministic:
+            return torch.zeros(1)
+        if other is None:
+            return 0.5 * torch.sum(self.mean ** 2 + self.var - 1.0 - self.logvar, dim=[1, 2, 3])
+        return 0.5 * torch.sum((self.mean - other.mean) ** 2 / other.var + self.var / other.var - 1.0 -
+                               self.logvar + other.logvar, dim=[1, 2, 3])
 
 
 class AutoencoderKL(ParamTree):
@@ -31,6 +63,8 @@ class AutoencoderKL(ParamTree):
             self.monitor = monitor
         self._packed = None
         self._plans = {}
+        self._packed_enc = None
+        self._enc_plans = {}
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
 
@@ -75,12 +109,42 @@ class AutoencoderKL(ParamTree):
         with torch.cuda.device(pl.dev):
             return pl.run(z).clone()
 
-    def encode(self, x):
-        raise NotImplementedError("AutoencoderKL.encode (VAE encoder) is scheduled after the denoising hot path "
-                                  "(SURVEY.md §8f-2); only decode() is implemented on the HIP kernels")
+    def _encode_plan(self, B, H, W):
+        from ._lib import get_context
+        from .engine import PackedVAEEncoder, VAEEncodePlan
+        p = next(self.parameters())
+        if p.device.type != "cuda":
+            raise RuntimeError("upgpt_amd.AutoencoderKL.encode runs only on the MI355X HIP path (parameters are on "
+                               "%s); there is no CPU fallback" % p.device)
+        ctx = get_context(p.device)
+        fp = weights_fingerprint(self)
+        if self._packed_enc is None or self._packed_enc[0] != fp:
+            params = dict(self.named_parameters())
+            with torch.cuda.device(p.device):
+                self._packed_enc = (fp, PackedVAEEncoder(ctx, self.arch, lambda n: params[n].data))
+            self._enc_plans = {}
+        key = (B, H, W)
+        if key not in self._enc_plans:
+            if len(self._enc_plans) >= 4:
+                self._enc_plans.pop(next(iter(self._enc_plans)))
+            with torch.cuda.device(p.device):
+                self._enc_plans[key] = VAEEncodePlan(ctx, self._packed_enc[1], B, H, W)
+                self._enc_plans[key].apply_tuning(tune_missing=os.environ.get("UPGPT_AUTOTUNE", "0") == "1")
+        return self._enc_plans[key]
 
+    @torch.no_grad()
+    def encode(self, x):
+        """x [B, 3, H, W] in [-1, 1] -> DiagonalGaussianDistribution over z (autoencoder.py:324-328)."""
+        B, c, H, W = x.shape
+        pl = self._encode_plan(B, H, W)
+        with torch.cuda.device(pl.dev):
+            return DiagonalGaussianDistribution(pl.run(x).clone())
+
+    @torch.no_grad()
     def forward(self, input, sample_posterior=True):
-        raise NotImplementedError("AutoencoderKL.forward needs encode(); see encode()")
+        posterior = self.encode(input)
+        z = posterior.sample() if sample_posterior else posterior.mode()
+        return self.decode(z), posterior
 
     def get_last_layer(self):
         return self.decoder.conv_out.weight
