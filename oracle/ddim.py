@@ -45,3 +45,45 @@ def ddim_sample(eps_fn, alphas_cumprod_f32, shape, S, eta, x_T, noise=None, temp
             inter["x_inter"].append(img)
             inter["pred_x0"].append(pred_x0)
     return img, inter
+
+
+@torch.no_grad()
+def plms_sample(eps_fn, alphas_cumprod_f32, shape, S, x_T, cond=None, log_every_t=100, num_ddpm=1000):
+    """ldm/models/diffusion/plms.py:114-236 (eta = 0): the DDIM update applied to an
+    Adams-Bashforth combination of the current and up to three previous eps; the first step
+    is a pseudo improved Euler step with one extra model evaluation at (x_prev, t_next)."""
+    b = shape[0]
+    ts, a, ap, sig, sq1m = ddim_step_coefficients(alphas_cumprod_f32, S, 0.0, num_ddpm)
+    time_range = np.flip(ts)
+    total = ts.shape[0]
+    img = x_T
+    inter = {"x_inter": [img], "pred_x0": [img]}
+    old = []
+
+    def update(x, e, index):
+        a_t = torch.full((b, 1, 1, 1), float(a[index]))
+        a_prev = torch.full((b, 1, 1, 1), float(ap[index]))
+        sq = torch.full((b, 1, 1, 1), float(sq1m[index]))
+        pred_x0 = (x - sq * e) / a_t.sqrt()
+        return a_prev.sqrt() * pred_x0 + (1.0 - a_prev).sqrt() * e, pred_x0
+
+    for i, step in enumerate(time_range):
+        index = total - i - 1
+        t = torch.full((b,), int(step), dtype=torch.long)
+        t_next = torch.full((b,), int(time_range[min(i + 1, len(time_range) - 1)]), dtype=torch.long)
+        e_t = eps_fn(img, t, cond)
+        if len(old) == 0:
+            x_prev, _ = update(img, e_t, index)
+            e_p = (e_t + eps_fn(x_prev, t_next, cond)) / 2
+        elif len(old) == 1:
+            e_p = (3 * e_t - old[-1]) / 2
+        elif len(old) == 2:
+            e_p = (23 * e_t - 16 * old[-1] + 5 * old[-2]) / 12
+        else:
+            e_p = (55 * e_t - 59 * old[-1] + 37 * old[-2] - 9 * old[-3]) / 24
+        img, pred_x0 = update(img, e_p, index)
+        old = (old + [e_t])[-3:]
+        if index % log_every_t == 0 or index == total - 1:
+            inter["x_inter"].append(img)
+            inter["pred_x0"].append(pred_x0)
+    return img, inter

@@ -237,6 +237,25 @@ def gen_encode(kind, out):
     print("encode", kind, "->", out, g["moments"].shape)
 
 
+def gen_plms(kind, out):
+    """PLMSSampler goldens: final latents of a 10-step run."""
+    import ldm.models.diffusion.plms as ref_plms
+    assert ref_plms.__file__.startswith(REF)
+    ref_plms.PLMSSampler.register_buffer = lambda self, n, a: setattr(self, n, a)
+    model, params = build_reference(kind)
+    C = params["channels"]
+    ntok = 87 if kind != "upscale" else 86
+    B = 2 if kind == "tiny" else 1
+    inp = synth.synth_inputs(2, (32, 24), C, ntok, 768, seed=0, concat_channels=1 if kind != "upscale" else 3, steps=10)
+    cond = {"c_crossattn": inp["c_crossattn"][:B], "c_concat": [inp["c_concat"][:B]]}
+    sampler = ref_plms.PLMSSampler(model)
+    z, inter = sampler.sample(S=10, batch_size=B, shape=(C, 32, 24), conditioning=cond, eta=0.0,
+                              x_T=inp["x_T"][:B].clone(), verbose=False, log_every_t=2)
+    np.savez_compressed(out, z=z.numpy(), pred_x0_last=inter["pred_x0"][-1].numpy(),
+                        n_inter=np.asarray(len(inter["x_inter"])))
+    print("plms", kind, "->", out, z.shape)
+
+
 def gen_schedule(out):
     g = {}
     for name, (ls, le) in {"bbox": (0.00085, 0.012), "upscale": (0.0001, 0.02)}.items():
@@ -267,9 +286,12 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    kinds = [a.only] if a.only else ["schedule", "tiny", "bbox", "upscale", "encode"]
+    kinds = [a.only] if a.only else ["schedule", "tiny", "bbox", "upscale", "encode", "plms"]
     for k in kinds:
-        if k == "encode":
+        if k == "plms":
+            for kind in ("tiny", "bbox"):
+                gen_plms(kind, os.path.join(HERE, "plms_%s.npz" % kind))
+        elif k == "encode":
             for kind in ("tiny", "bbox", "upscale"):
                 gen_encode(kind, os.path.join(HERE, "encode_%s.npz" % kind))
         elif k == "schedule":

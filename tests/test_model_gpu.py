@@ -250,3 +250,22 @@ def test_log_images_returns_reconstruction_and_img2img_decode():
     cond = {"c_crossattn": c["c_crossattn"], "c_concat": c["c_concat"]}
     out = s.decode(z_enc, cond, t_enc)
     assert out.shape == z.shape and torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("kind", ["tiny", "bbox"])
+def test_plms_sampler_vs_reference_golden(kind):
+    """PLMSSampler (ldm.models.diffusion.plms surface) on the HIP path vs the reference's latents."""
+    from ldm.models.diffusion.plms import PLMSSampler
+    model, _ = get_model(kind)
+    g = np.load(os.path.join(G, "plms_%s.npz" % kind))
+    k = KIND[kind]
+    B = 2 if kind == "tiny" else 1
+    inp = inputs(kind, 2)
+    cond = {"c_crossattn": inp["c_crossattn"][:B].cuda(), "c_concat": [inp["c_concat"][:B].cuda()]}
+    z, inter = PLMSSampler(model).sample(S=10, batch_size=B, shape=(k["C"], 32, 24), conditioning=cond, eta=0.0,
+                                         x_T=inp["x_T"][:B].cuda(), verbose=False, log_every_t=2)
+    e = mse(z, g["z"])
+    print("%s PLMS 10-step latent MSE %.3e" % (kind, e))
+    assert e < 1e-3 and len(inter["x_inter"]) == int(g["n_inter"])
+    with pytest.raises(ValueError):
+        PLMSSampler(model).sample(S=10, batch_size=B, shape=(k["C"], 32, 24), conditioning=cond, eta=0.5)

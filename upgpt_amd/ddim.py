@@ -236,6 +236,15 @@ class DDIMSampler(object):
             assert self.model.parameterization == "eps"
             e_t = score_corrector.modify_score(self.model, e_t, x, t, c, **corrector_kwargs)
 
+        if quantize_denoised:
+            raise NotImplementedError("quantize_denoised needs a VQ first stage (not on the UPGPT path)")
+        return self._ddim_update(x, e_t, index, use_original_steps=use_original_steps, temperature=temperature,
+                                 noise_dropout=noise_dropout, repeat_noise=repeat_noise, noise=noise)
+
+    def _ddim_update(self, x, e_t, index, use_original_steps=False, temperature=1., noise_dropout=0.,
+                     repeat_noise=False, noise=None):
+        """(x_prev, pred_x0) of ddim.py:189-203 for DDIM index `index`, in upk_ddim_step_f32."""
+        b, device = x.shape[0], x.device
         if use_original_steps:
             alphas, alphas_prev = self.model.alphas_cumprod, self.model.alphas_cumprod_prev
             sqrt_1m, sigmas = self.model.sqrt_one_minus_alphas_cumprod, self.ddim_sigmas_for_original_num_steps
@@ -244,13 +253,14 @@ class DDIMSampler(object):
             sqrt_1m, sigmas = self.ddim_sqrt_one_minus_alphas, self.ddim_sigmas
         scal = lambda v: float(torch.as_tensor(v[index]).float())  # fp32 rounding, like torch.full(...)
         a_t, a_prev, sigma_t, sq1m = scal(alphas), scal(alphas_prev), scal(sigmas), scal(sqrt_1m)
-        if quantize_denoised:
-            raise NotImplementedError("quantize_denoised needs a VQ first stage (not on the UPGPT path)")
-        if noise is None:
-            noise = noise_like(x.shape, device, repeat_noise)
-        noise = sigma_t * noise * temperature
-        if noise_dropout > 0.:
-            noise = torch.nn.functional.dropout(noise, p=noise_dropout)
+        nz = None
+        if sigma_t != 0. or noise is not None:
+            if noise is None:
+                noise = noise_like(x.shape, device, repeat_noise)
+            nz = sigma_t * noise * temperature
+            if noise_dropout > 0.:
+                nz = torch.nn.functional.dropout(nz, p=noise_dropout)
+            nz = nz.float().contiguous().reshape(1, -1)
         from ._lib import get_context
         ctx = get_context(device)
         coefs = ddim_coefficient_table([a_t], [a_prev], [sigma_t], [sq1m], [0]).to(device)
@@ -258,8 +268,7 @@ class DDIMSampler(object):
         pred_x0 = torch.empty_like(x_prev)
         C_, hw = x.shape[1], x.shape[2] * x.shape[3]
         with torch.cuda.device(device):
-            ctx.ddim_step(x_prev, e_t.float().contiguous(), coefs, noise.float().contiguous().reshape(1, -1), None,
-                          pred_x0, None, 0, b, C_, hw)
+            ctx.ddim_step(x_prev, e_t.float().contiguous(), coefs, nz, None, pred_x0, None, 0, b, C_, hw)
         return x_prev, pred_x0
 
     @torch.no_grad()

@@ -1,0 +1,115 @@
+"""PLMSSampler — drop-in for ldm.models.diffusion.plms.PLMSSampler: pseudo
+linear multistep (Adams-Bashforth on eps) over the same schedule tables as DDIM (eta must be 0).
+
+Round-1 state: runs on the general path — one UNetModel.forward (HIP kernels, eager launches)
+per model evaluation, the eps combination as tensor arithmetic and the x_prev / pred_x0 update
+in upk_ddim_step_f32.  The captured-graph fast path of DDIMSampler (device-side step counter,
+hoisted timestep MLP) is not wired for the eps history yet.
+"""
+import numpy as np
+import torch
+
+from .ddim import DDIMSampler
+
+# Adams-Bashforth weights on [e_t, e_{t-1}, e_{t-2}, e_{t-3}] by available history (plms.py:224-234)
+_AB = {1: (3 / 2, -1 / 2), 2: (23 / 12, -16 / 12, 5 / 12), 3: (55 / 24, -59 / 24, 37 / 24, -9 / 24)}
+
+
+class PLMSSampler(DDIMSampler):
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
+        if ddim_eta != 0:
+            raise ValueError("ddim_eta must be 0 for PLMS")
+        super().make_schedule(ddim_num_steps, ddim_discretize, ddim_eta, verbose)
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None,
+               img_callback=None, quantize_x0=False, eta=0., mask=None, x0=None, temperature=1., noise_dropout=0.,
+               score_corrector=None, corrector_kwargs=None, verbose=True, x_T=None, log_every_t=100,
+               unconditional_guidance_scale=1., unconditional_conditioning=None, **kwargs):
+        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
+        C, H, W = shape
+        size = (batch_size, C, H, W)
+        print(f"Data shape for PLMS sampling is {size}")
+        return self.plms_sampling(conditioning, size, callback=callback, img_callback=img_callback,
+                                  quantize_denoised=quantize_x0, mask=mask, x0=x0, noise_dropout=noise_dropout,
+                                  temperature=temperature, score_corrector=score_corrector,
+                                  corrector_kwargs=corrector_kwargs, x_T=x_T, log_every_t=log_every_t,
+                                  unconditional_guidance_scale=unconditional_guidance_scale,
+                                  unconditional_conditioning=unconditional_conditioning)
+
+    @torch.no_grad()
+    def plms_sampling(self, cond, shape, x_T=None, ddim_use_original_steps=False, callback=None, timesteps=None,
+                      quantize_denoised=False, mask=None, x0=None, img_callback=None, log_every_t=100,
+                      temperature=1., noise_dropout=0., score_corrector=None, corrector_kwargs=None,
+                      unconditional_guidance_scale=1., unconditional_conditioning=None):
+        if ddim_use_original_steps or quantize_denoised:
+            raise NotImplementedError("PLMS with the original 1000 steps / quantized x0 is not on the UPGPT path")
+        device = self.model.betas.device
+        b = shape[0]
+        img = torch.randn(shape, device=device) if x_T is None else x_T.to(device)
+        if timesteps is None:
+            timesteps = self.ddim_timesteps
+        else:
+            subset_end = int(min(timesteps / self.ddim_timesteps.shape[0], 1) * self.ddim_timesteps.shape[0]) - 1
+            timesteps = self.ddim_timesteps[:subset_end]
+        intermediates = {"x_inter": [img], "pred_x0": [img]}
+        time_range = np.flip(timesteps)
+        total = timesteps.shape[0]
+        print(f"Running PLMS Sampling with {total} timesteps")
+        history = []  # newest last, at most 3 entries
+        for i, step in enumerate(time_range):
+            index = total - i - 1
+            ts = torch.full((b,), int(step), device=device, dtype=torch.long)
+            ts_next = torch.full((b,), int(time_range[min(i + 1, len(time_range) - 1)]), device=device,
+                                 dtype=torch.long)
+            if mask is not None:
+                assert x0 is not None
+                img = self.model.q_sample(x0, ts) * mask + (1. - mask) * img
+            img, pred_x0, e_t = self.p_sample_plms(img, cond, ts, index=index, temperature=temperature,
+                                                   noise_dropout=noise_dropout, score_corrector=score_corrector,
+                                                   corrector_kwargs=corrector_kwargs,
+                                                   unconditional_guidance_scale=unconditional_guidance_scale,
+                                                   unconditional_conditioning=unconditional_conditioning,
+                                                   old_eps=history, t_next=ts_next)
+            history = (history + [e_t])[-3:]
+            if callback:
+                callback(i)
+            if img_callback:
+                img_callback(pred_x0, i)
+            if index % log_every_t == 0 or index == total - 1:
+                intermediates["x_inter"].append(img)
+                intermediates["pred_x0"].append(pred_x0)
+        return img, intermediates
+
+    @torch.no_grad()
+    def p_sample_plms(self, x, c, t, index, repeat_noise=False, use_original_steps=False, quantize_denoised=False,
+                      temperature=1., noise_dropout=0., score_corrector=None, corrector_kwargs=None,
+                      unconditional_guidance_scale=1., unconditional_conditioning=None, old_eps=None, t_next=None):
+        def model_eps(xx, tt):
+            if unconditional_conditioning is None or unconditional_guidance_scale == 1.:
+                e = self.model.apply_model(xx, tt, c)
+            else:
+                e_u, e = self.model.apply_model(torch.cat([xx] * 2), torch.cat([tt] * 2),
+                                                self._cat_cond(unconditional_conditioning, c)).chunk(2)
+                e = e_u + unconditional_guidance_scale * (e - e_u)
+            if score_corrector is not None:
+                assert self.model.parameterization == "eps"
+                e = score_corrector.modify_score(self.model, e, xx, tt, c, **corrector_kwargs)
+            return e
+
+        def update(e):  # the DDIM update with sigma = 0 (eta is forced to 0), fused kernel
+            return self._ddim_update(x, e, index, temperature=temperature, noise_dropout=noise_dropout,
+                                     repeat_noise=repeat_noise)
+
+        old_eps = old_eps or []
+        e_t = model_eps(x, t)
+        if len(old_eps) == 0:  # pseudo improved Euler: one extra evaluation at (x_prev, t_next)
+            x_prev, _ = update(e_t)
+            e_prime = (e_t + model_eps(x_prev, t_next)) / 2
+        else:
+            w = _AB[min(len(old_eps), 3)]
+            e_prime = w[0] * e_t
+            for k in range(1, len(w)):
+                e_prime = e_prime + w[k] * old_eps[-k]
+        x_prev, pred_x0 = update(e_prime)
+        return x_prev, pred_x0, e_t
