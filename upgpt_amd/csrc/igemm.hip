@@ -50,6 +50,7 @@ struct IgemmArgs {
   int HL, WL;      // logical input dims (after optional 2x upsample)
   int Ho, Wo;
   int ks, stride, pad_lo, ups;
+  int linear;      // ks == 1 && stride == 1 && !ups: rows are addressed directly
   int cpt;         // 32-wide chunks per tap = (c1+c2)/32
   int nchunks;     // ks*ks*cpt
   int chunks_per_split;
@@ -213,12 +214,18 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
     const int m = m0 + row;
     a_ok[i] = (row < BM) && (m < a.M);
     const int mm = a_ok[i] ? m : 0;
-    const int b = mm / HoWo;
-    const int p = mm - b * HoWo;
-    const int oy = p / a.Wo;
-    a_b[i] = b;
-    a_oy[i] = oy * a.stride - a.pad_lo;
-    a_ox[i] = (p - oy * a.Wo) * a.stride - a.pad_lo;
+    if (a.linear) {  // 1x1 / Linear: the "pixel" is the row itself (no integer divisions)
+      a_b[i] = 0;
+      a_oy[i] = 0;
+      a_ox[i] = mm;
+    } else {
+      const int b = mm / HoWo;
+      const int p = mm - b * HoWo;
+      const int oy = p / a.Wo;
+      a_b[i] = b;
+      a_oy[i] = oy * a.stride - a.pad_lo;
+      a_ox[i] = (p - oy * a.Wo) * a.stride - a.pad_lo;
+    }
   }
 
   f16x8 ra[KS][A_IT], rb[KS][B_IT];
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
       const int ch = (tid + i * NT) & 3;
       int iy = a_oy[i] + ky;
       int ix = a_ox[i] + kx;
-      tap_ok[i] = a_ok[i] && iy >= 0 && iy < a.HL && ix >= 0 && ix < a.WL;
+      tap_ok[i] = a_ok[i] && (a.linear || (iy >= 0 && iy < a.HL && ix >= 0 && ix < a.WL));
       if (a.ups) {
         iy >>= 1;
         ix >>= 1;
@@ -464,12 +471,18 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
       const int m = m0 + rg * 16 + r16;
       a_ok[i] = (rg < AG) && (m < a.M);
       const int mm = a_ok[i] ? m : 0;
-      const int b = mm / HoWo;
-      const int p = mm - b * HoWo;
-      const int oy = p / a.Wo;
-      a_b[i] = b;
-      a_oy[i] = oy * a.stride - a.pad_lo;
-      a_ox[i] = (p - oy * a.Wo) * a.stride - a.pad_lo;
+      if (a.linear) {  // 1x1 / Linear: the "pixel" is the row itself (no integer divisions)
+        a_b[i] = 0;
+        a_oy[i] = 0;
+        a_ox[i] = mm;
+      } else {
+        const int b = mm / HoWo;
+        const int p = mm - b * HoWo;
+        const int oy = p / a.Wo;
+        a_b[i] = b;
+        a_oy[i] = oy * a.stride - a.pad_lo;
+        a_ox[i] = (p - oy * a.Wo) * a.stride - a.pad_lo;
+      }
     }
     const int ctot = a.c1 + a.c2;
     int cur_kc = kc0, cur_c0, cur_ky, cur_kx;
@@ -487,7 +500,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
       for (int i = 0; i < AGW; ++i) {
         int iy = a_oy[i] + ky;
         int ix = a_ox[i] + kx;
-        tap_ok[i] = a_ok[i] && iy >= 0 && iy < a.HL && ix >= 0 && ix < a.WL;
+        tap_ok[i] = a_ok[i] && (a.linear || (iy >= 0 && iy < a.HL && ix >= 0 && ix < a.WL));
         if (a.ups) {
           iy >>= 1;
           ix >>= 1;
@@ -821,6 +834,7 @@ extern "C" int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_str
   }
   a.M = a.B * a.Ho * a.Wo;
   if (a.M <= 0) return upk_fail(ctx, UPK_EINVAL, "conv: empty output");
+  a.linear = (a.ks == 1 && a.stride == 1 && !a.ups) ? 1 : 0;
   a.cpt = (a.c1 + a.c2) / 32;
   a.nchunks = a.ks * a.ks * a.cpt;
   a.flags = flags;

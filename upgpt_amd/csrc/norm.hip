@@ -20,7 +20,7 @@
 
 namespace {
 
-constexpr int GN_MAX_CHUNKS = 64;
+constexpr int GN_MAX_CHUNKS = 32;
 constexpr int GN_GROUPS_MAX = 32;
 constexpr int GN_PREF = 4;  // x vectors prefetched per thread in gn_apply
 
@@ -121,6 +121,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a, int rows_
       pre[k] = gn_load(a, (long)b * a.hw + p0 + pr, i - pr * vpr);
     }
   }
+  // gamma / beta of this thread's channels: cold parameters (HBM latency), requested up front
+  constexpr int GB = 8;  // C <= 2048 -> <= 8 channels per thread
+  float pg[GB], pb[GB];
+#pragma unroll
+  for (int k = 0; k < GB; ++k) {
+    const int ch = tid + k * 256;
+    pg[k] = ch < C ? a.gamma[ch] : 0.f;
+    pb[k] = ch < C ? a.beta[ch] : 0.f;
+  }
   // fixed-order (bitwise reproducible) reduction of the chunk partials, 4 threads per
   // (group, sum|sumsq) so that the <= 64 loads per quantity are issued in parallel.
   {
@@ -128,8 +137,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a, int rows_
     const int q = tid >> 2, sub = tid & 3;  // q = group*2 + which
     if (q < a.groups * 2) {
       const float* w = a.ws + (long)b * a.nchunks * a.groups * 2 + q;
+      // all (<= 16) partial loads are issued before the first add: a runtime-trip-count
+      // "load, accumulate" loop is compiled into that many DEPENDENT L2 round trips
+      float v[GN_MAX_CHUNKS / 4];
+#pragma unroll
+      for (int k = 0; k < GN_MAX_CHUNKS / 4; ++k) {
+        const int idx = sub + 4 * k;
+        v[k] = idx < a.nchunks ? w[(long)idx * a.groups * 2] : 0.f;
+      }
       double acc = 0.0;
-      for (int k = sub; k < a.nchunks; k += 4) acc += (double)w[(long)k * a.groups * 2];
+#pragma unroll
+      for (int k = 0; k < GN_MAX_CHUNKS / 4; ++k) acc += (double)v[k];
       part[tid] = acc;
     }
     __syncthreads();
@@ -147,11 +165,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a, int rows_
   __syncthreads();
   float* scale = tab;
   float* shift = tab + C;
-  for (int ch = tid; ch < C; ch += 256) {
-    const int g = ch / a.cpg;
-    const float sc = srstd[g] * a.gamma[ch];
-    scale[ch] = sc;
-    shift[ch] = a.beta[ch] - smean[g] * sc;
+#pragma unroll
+  for (int k = 0; k < GB; ++k) {
+    const int ch = tid + k * 256;
+    if (ch < C) {
+      const int g = ch / a.cpg;
+      const float sc = srstd[g] * pg[k];
+      scale[ch] = sc;
+      shift[ch] = pb[k] - smean[g] * sc;
+    }
   }
   __syncthreads();
   auto emit = [&](int i, const f16x8 xv) {
@@ -287,8 +309,9 @@ extern "C" int upk_groupnorm_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int 
   hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nchunks, batch), dim3(256), 0, stream, a);
   int rc = upk_check_launch(ctx, "gn_stats");
   if (rc) return rc;
-  // apply: ~16 KB of fp16 per block
-  int rows = (8192 + C - 1) / C;
+  // apply: ~4 KB of fp16 per block (>= 3 blocks per CU on the UNet shapes: the kernel is a chain of
+  // dependent memory round trips, so it needs co-resident blocks, not long per-block loops)
+  int rows = (2048 + C - 1) / C;
   if (rows < 1) rows = 1;
   const int blocks = (hw + rows - 1) / rows;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, batch), dim3(256), (size_t)C * 2 * sizeof(float), stream, a, rows);
