@@ -269,3 +269,46 @@ def test_plms_sampler_vs_reference_golden(kind):
     assert e < 1e-3 and len(inter["x_inter"]) == int(g["n_inter"])
     with pytest.raises(ValueError):
         PLMSSampler(model).sample(S=10, batch_size=B, shape=(k["C"], 32, 24), conditioning=cond, eta=0.5)
+
+
+def test_square_latent_32x32_vs_oracle():
+    """BASELINE.json words the metric on 256x256 px = latent 4x32x32 (the bench workload); the UNet is
+    fully convolutional, so the same weights are checked against the oracle at that shape."""
+    model, sd = get_model("bbox")
+    inp = synth.synth_inputs(1, (32, 32), 4, 87, 768, seed=2)
+    t = torch.tensor([601])
+    x = torch.cat([inp["x_T"], inp["c_concat"]], 1)
+    ref = o_unet.unet_forward(sd, synth.BBOX_UNET, x, t, inp["c_crossattn"])
+    got = model.apply_model(inp["x_T"].cuda(), t.cuda(),
+                            {"c_crossattn": inp["c_crossattn"].cuda(), "c_concat": [inp["c_concat"].cuda()]})
+    assert got.shape == (1, 4, 32, 32) and mse(got, ref) < 1e-4
+
+
+def test_upscale_model_config_true_size_vs_oracle():
+    """BASELINE config 5 at its config-true latent 3x128x96: self-attention over
+    n = 3072 tokens never materialises the 3072^2 score matrix."""
+    model, sd = get_model("upscale")
+    inp = synth.synth_inputs(1, (128, 96), 3, 86, 768, seed=4, concat_channels=3)
+    t = torch.tensor([801])
+    x = torch.cat([inp["x_T"], inp["c_concat"]], 1)
+    ref = o_unet.unet_forward(sd, synth.UPSCALE_UNET, x, t, inp["c_crossattn"])
+    got = model.apply_model(inp["x_T"].cuda(), t.cuda(),
+                            {"c_crossattn": inp["c_crossattn"].cuda(), "c_concat": [inp["c_concat"].cuda()]})
+    assert got.shape == (1, 3, 128, 96)
+    e = mse(got, ref)
+    print("upscale 128x96 eps MSE %.3e (|ref| max %.2f)" % (e, float(ref.abs().max())))
+    assert e < 1e-4
+
+
+def test_invalid_shapes_fail_loudly():
+    model, _ = get_model("tiny")
+    inp = synth.synth_inputs(1, (20, 12), 4, 87, 768, seed=0)  # 20x12 is not divisible by 8
+    with pytest.raises(ValueError, match="multiples of 8"):
+        model.apply_model(inp["x_T"].cuda(), torch.tensor([5]).cuda(),
+                          {"c_crossattn": inp["c_crossattn"].cuda(), "c_concat": [inp["c_concat"].cuda()]})
+    ok = synth.synth_inputs(1, (32, 24), 4, 87, 768, seed=0)
+    with pytest.raises(AssertionError):  # wrong context width
+        model.model.diffusion_model(torch.cat([ok["x_T"], ok["c_concat"]], 1).cuda(), torch.tensor([5]).cuda(),
+                                    context=torch.zeros(1, 87, 512).cuda())
+    with pytest.raises(AssertionError):  # wrong channel count
+        model.model.diffusion_model(ok["x_T"].cuda(), torch.tensor([5]).cuda(), context=ok["c_crossattn"].cuda())

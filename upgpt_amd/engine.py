@@ -448,6 +448,12 @@ class UNetPlan(Emitter):
     def _res(self, P, Lr, x, skip):
         w, v = self.pk.w, self.pk.v
         n = Lr.name
+        if skip is not None and (skip.H, skip.W, skip.B) != (x.H, x.W, x.B):
+            # the reference fails in torch.cat here (openaimodel.py:736) when H or W is not a
+            # multiple of 2^(levels-1); fail just as loudly instead of reading mismatched rows
+            raise ValueError("UNet skip connection %dx%d does not match the decoder feature map %dx%d at %s: "
+                             "latent height and width must be multiples of %d" % (
+                                 skip.H, skip.W, x.H, x.W, n, 2 ** (len(self.arch.channel_mult) - 1)))
         g, b = v[n + ".in_layers.0"]
         hN = self.groupnorm(P, x, g, b, 1e-5, True, self.gn_ws, x2=skip)
         hh = self.conv(P, hN, w[n + ".in_layers.2"], **self._rv(n))
