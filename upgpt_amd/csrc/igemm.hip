@@ -429,7 +429,15 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 template <int MI, int NI, int WM, int WN, int KS, int NBUF>
 __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
-  static_assert(WM * WN == 4, "4 consumer waves");
+  // WM*WN == 4: the 4 MFMA waves tile the block in M x N (each a MI x NI register tile).
+  // WM*WN == 1: K-SPLIT mode — every MFMA wave owns the WHOLE MI x NI block tile and takes every
+  // 4th K-chunk; the four accumulators are summed through LDS once at the end (fixed order).
+  // Small block tiles (more workgroups for the 256 CUs) then keep a square-ish register tile:
+  // LDS read traffic per MFMA is (MI+NI)/(MI*NI) KiB instead of the same figure for a
+  // 4x smaller wave tile — the M x N split of a 64x112 block is LDS-bandwidth bound.
+  static_assert(WM * WN == 4 || WM * WN == 1, "4 consumer waves");
+  constexpr bool KSPLIT = (WM * WN == 1);
+  static_assert(!KSPLIT || KS % 4 == 0, "K-split needs KS % 4 == 0");
   constexpr int BM = MI * 16 * WM;
   constexpr int BN = NI * 16 * WN;
   constexpr int AG = BM / 16, BG = BN / 16;          // 16-row groups (1 KiB = one wave DMA)
@@ -572,7 +580,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
     for (int t = 0; t < nstages; ++t) {
       // slot (t + D) % NBUF held stage t - 1: its readers passed the barrier that ended iteration t-1
       if (issued < nstages) {
-        issue_stage(issued % NBUF);
+        if (!(a.flags & ABL_NOGLOAD)) issue_stage(issued % NBUF);
         ++issued;
       }
       const int outstanding = issued - (t + 1);  // stages t+1 .. issued-1
@@ -583,8 +591,8 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
   }
 
   // ================================ consumers ================================
-  const int wm = wave / WN;
-  const int wn = wave - wm * WN;
+  const int wm = KSPLIT ? 0 : wave / WN;
+  const int wn = KSPLIT ? 0 : wave - wm * WN;
   const int lg = lane >> 4;
   const int lc = lane & 15;
   f32x4 acc[MI][NI];
@@ -600,7 +608,8 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
   for (int t = 0; t < nstages; ++t) {
     const f16* slot = smem + (t % NBUF) * STAGE;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
+    for (int s0 = 0; s0 < (KSPLIT ? KS / 4 : KS); ++s0) {
+      const int s = KSPLIT ? wave + 4 * s0 : s0;  // K-split: this wave's chunks of the stage
       const f16* tA = slot + s * ROWS * 32 + a_base;
       const f16* tB = slot + s * ROWS * 32 + b_base;
       f16x8 fa[MI], fb[NI];
@@ -608,18 +617,71 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
       for (int i = 0; i < MI; ++i) fa[i] = *(const f16x8*)(tA + i * 512);
 #pragma unroll
       for (int j = 0; j < NI; ++j) fb[j] = *(const f16x8*)(tB + j * 512);
+      if (!(a.flags & ABL_NOMFMA)) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(fb[j]));
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // our LDS reads are done before the slot is reused
     __builtin_amdgcn_s_barrier();
   }
 
+  if constexpr (KSPLIT) {
+    // ---- sum the 4 K-slices through LDS (the ring is free: all consumers passed the last barrier)
+    constexpr int NF = MI * NI;
+    static_assert(NF * 4096 <= NBUF * STAGE * 2, "reduction buffer must fit in the ring");
+    float* red = (float*)smem;  // [4 waves][NF fragments][64 lanes][4]
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) *(f32x4*)(red + ((wave * NF + i * NI + j) * 64 + lane) * 4) = acc[i][j];
+    __syncthreads();  // MFMA waves only: the loader waves have already ended
+    if (a.flags & ABL_NOEPI) return;
+    auto frag_sum = [&](int f) {
+      f32x4 v = *(const f32x4*)(red + ((0 * NF + f) * 64 + lane) * 4);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) v += *(const f32x4*)(red + ((w * NF + f) * 64 + lane) * 4);
+      return v;
+    };
+    float* slab = a.partial ? a.partial + (long)blockIdx.z * a.M * a.npad : nullptr;
+    for (int f = wave; f < NF; f += 4) {  // fragment f = (i, j) is finished by wave f % 4
+      const int i = f / NI, j = f - i * NI;
+      const int m = m0 + i * 16 + lc;
+      const int n = n0 + j * 16 + lg * 4;
+      if (n >= a.npad) continue;
+      if (slab) {
+        if (m < a.M) *(f32x4*)(slab + (unsigned)m * (unsigned)a.npad + n) = frag_sum(f);
+        continue;
+      }
+      const RowCtx rc = Epi::row(a, m);
+      if (a.flags & UPK_F_GEGLU) {
+        if ((j & 2) == 0 && j + 2 < NI) Epi::store(a, rc, n, frag_sum(f), frag_sum(f + 2));
+      } else {
+        const f32x4 v = frag_sum(f);
+        Epi::store(a, rc, n, v, v);
+      }
+    }
+    return;
+  }
   const int mw = m0 + wm * (MI * 16);
   const int nw = n0 + wn * (NI * 16);
+  if (a.flags & ABL_NOEPI) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (t == 123.456f) ((float*)a.y)[0] = t;
+    return;
+  }
   if (a.partial) {
     float* slab = a.partial + (long)blockIdx.z * a.M * a.npad;
 #pragma unroll
@@ -712,6 +774,9 @@ const CfgInfo kCfgs[] = {
     CFGW(2, 4, 4, 1, 2, 3), CFGW(1, 4, 4, 1, 4, 3),
     CFGW(4, 7, 2, 2, 2, 3), CFGW(2, 7, 2, 2, 2, 3), CFGW(1, 7, 2, 2, 2, 3),
     CFGW(2, 7, 4, 1, 2, 3), CFGW(1, 7, 4, 1, 4, 3), CFGW(2, 2, 2, 2, 2, 3), CFGW(1, 7, 4, 1, 2, 3),
+    // K-split across the MFMA waves (WM = WN = 1): block tile == register tile
+    CFGW(2, 7, 1, 1, 4, 3), CFGW(4, 7, 1, 1, 4, 3), CFGW(2, 4, 1, 1, 4, 3), CFGW(4, 4, 1, 1, 4, 3),
+    CFGW(2, 2, 1, 1, 4, 3), CFGW(4, 2, 1, 1, 4, 3), CFGW(1, 7, 1, 1, 4, 3), CFGW(4, 8, 1, 1, 4, 3),
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -721,15 +786,16 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // cache (upgpt_amd/tuned_gfx950.json holds measured choices for the bench shapes).
 double estimate(const CfgInfo& c, int M, int npad, int nchunks, int splitk, int cus, bool geglu) {
   const int BM = c.mi * 16 * c.wm, BN = c.ni * 16 * c.wn;
-  const int waves = c.wm * c.wn;
+  const bool ksplit = c.nbuf && c.wm * c.wn == 1;  // 4 MFMA waves share the tile and split K
+  const int waves = ksplit ? 4 : c.wm * c.wn;
   if (geglu && ((c.ni * 16) % 64 != 0)) return 1e30;
   const int tiles = cdiv(M, BM) * cdiv(npad, BN);
   const long wgs = (long)tiles * splitk;
   const int chunks = cdiv(nchunks, splitk);
   const int stages = cdiv(chunks, c.ks);
   // per K-chunk cycles of one workgroup
-  const double mfma = c.mi * c.ni * 16.0 * (waves > 4 ? waves / 4.0 : 1.0);
-  const double lds = (c.mi + c.ni) * 4.0 * waves + (BM + BN) * 4 * 13.0 / 64.0 / 4.0;
+  const double mfma = c.mi * c.ni * 16.0 * (waves > 4 ? waves / 4.0 : 1.0) / (ksplit ? 4.0 : 1.0);
+  const double lds = (c.mi + c.ni) * 4.0 * (ksplit ? 1 : waves) + (c.nbuf ? 0.0 : (BM + BN) * 4 * 13.0 / 64.0 / 4.0);
   const double gl = (BM + BN) * 64.0 / 40.0;  // bytes / (B/clk/CU sustained from L2)
   const double work = fmax(fmax(mfma, lds), gl) * c.ks;
   // workgroups resident per CU (LDS + registers), they overlap each other's stalls
