@@ -610,6 +610,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
 #pragma unroll
     for (int s0 = 0; s0 < (KSPLIT ? KS / 4 : KS); ++s0) {
       const int s = KSPLIT ? wave + 4 * s0 : s0;  // K-split: this wave's chunks of the stage
+      if (a.flags & ABL_NOLDSW) continue;  // (ablation: no LDS reads either)
       const f16* tA = slot + s * ROWS * 32 + a_base;
       const f16* tB = slot + s * ROWS * 32 + b_base;
       f16x8 fa[MI], fb[NI];
