@@ -14,6 +14,13 @@ d = L.ConvDesc()
 d.x1 = x.data_ptr(); d.c1 = cin; d.ld1 = cin; d.batch = B; d.in_h = H; d.in_w = W; d.ksize = ks; d.stride = 1
 d.w_packed = wp.data_ptr(); d.n_out = cout; d.n_pad = n_pad; d.y = y.data_ptr(); d.ldy = cout
 d.tune_cfg = cfg + 1; d.tune_splitk = sk
+epi = os.environ.get("EPI", "")  # e.g. EPI=bias,res
+if "bias" in epi:
+    bias = torch.randn(n_pad, device="cuda"); d.bias = bias.data_ptr()
+if "geglu" in epi:
+    d.flags = 2; d.n_out = cout // 2; d.ldy = cout // 2
+if "res" in epi:
+    res = torch.randn(B * H * W, cout, device="cuda").half(); d.residual = res.data_ptr(); d.ld_res = cout
 ctx.conv(d); torch.cuda.synchronize()
 s = torch.cuda.Stream()
 with torch.cuda.stream(s):

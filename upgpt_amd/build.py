@@ -41,6 +41,7 @@ def build(force=False, verbose=True):
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
              "-Wno-unused-result", "-I", os.path.join(HERE, "..", "include")]
+    flags += os.environ.get("UPK_CXXFLAGS", "").split()  # dev builds, e.g. -DUPK_TIMELINE (scripts/timeline.py)
 
     def cc(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))

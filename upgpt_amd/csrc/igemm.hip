@@ -25,7 +25,14 @@
 namespace {
 
 // debug-only ablation bits (env UPK_ABLATE, read per launch): which phase owns the time?
-enum { ABL_NOEPI = 0x10000, ABL_NOGLOAD = 0x20000, ABL_NOLDSW = 0x40000, ABL_NOMFMA = 0x80000 };
+enum {
+  ABL_NOEPI = 0x10000,
+  ABL_NOGLOAD = 0x20000,
+  ABL_NOLDSW = 0x40000,
+  ABL_NOMFMA = 0x80000,
+  ABL_EMPTY = 0x100000,  // WS kernel returns at entry (pure launch cost of its geometry)
+  ABL_TIMELINE = 0x200000,  // WS kernel: blocks 0 and gridDim.x-1 write s_memtime stamps to the workspace
+};
 
 struct IgemmArgs {
   const f16* x1;
@@ -51,6 +58,7 @@ struct IgemmArgs {
   int Ho, Wo;
   int ks, stride, pad_lo, ups;
   int linear;      // ks == 1 && stride == 1 && !ups: rows are addressed directly
+  unsigned long long* dbg;  // ABL_TIMELINE stamps
   int cpt;         // 32-wide chunks per tap = (c1+c2)/32
   int nchunks;     // ks*ks*cpt
   int chunks_per_split;
@@ -100,26 +108,51 @@ struct Epi {
     return r;
   }
 
-  // stores packed columns [n, n+4) of the row; v = value accumulators, g = gate (GEGLU)
-  static __device__ __forceinline__ void store(const IgemmArgs& a, const RowCtx& r, int n, f32x4 v, f32x4 g) {
+  // Epilogue operands of one (row, 4-column) fragment.  They are FETCHED for a whole batch of
+  // fragments before the first store of the batch: with load -> convert -> store per fragment the
+  // stores (which may alias the residual as far as the compiler knows) serialise the loads, and a
+  // 7-fragment epilogue costs seven dependent L2/fabric round trips (measured 2.2-3.5 us of a
+  // 5-16 us launch with in-kernel s_memtime stamps).
+  struct In {
+    f32x4 rv;
+    f16x4 res;
+  };
+  static __device__ __forceinline__ f32x4 bias4(const IgemmArgs& a, int n) {
+    return (a.bias && n < a.npad) ? *(const f32x4*)(a.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  static __device__ __forceinline__ int out_col(const IgemmArgs& a, int n) {
+    return (a.flags & UPK_F_GEGLU) ? (n >> 6) * 32 + (n & 31) : n;
+  }
+  static __device__ __forceinline__ In fetch(const IgemmArgs& a, const RowCtx& r, int n) {
+    In in;
+    in.rv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    in.res = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+    if (!r.ok || n >= a.npad) return in;
+    const int oc = out_col(a, n);
+    const bool to_vt = a.vt && n >= a.vt_from;
+    if (oc >= a.n_out && !to_vt) return in;
+    if (a.rowvec) in.rv = *(const f32x4*)(a.rowvec + r.rv_off + n);
+    if (a.res && !to_vt) in.res = *(const f16x4*)(a.res + r.res_off + oc);
+    return in;
+  }
+
+  // finishes and stores packed columns [n, n+4) of the row; v = value accumulators, g = gate
+  // (GEGLU) with their biases bv / bg, `in` = the operands fetched above
+  static __device__ __forceinline__ void store(const IgemmArgs& a, const RowCtx& r, int n, f32x4 v, f32x4 g,
+                                               const f32x4 bv, const f32x4 bg, const In& in) {
     if (!r.ok) return;
     const int flags = a.flags;
-    int oc = n;  // output column
+    v += bv;
     if (flags & UPK_F_GEGLU) {
       // packed rows: [32 value | 32 gate] per 64-row block
-      if (a.bias) {
-        v += *(const f32x4*)(a.bias + n);
-        g += *(const f32x4*)(a.bias + n + 32);
-      }
+      g += bg;
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = v[k] * upk_gelu(g[k]);
-      oc = (n >> 6) * 32 + (n & 31);
-    } else if (a.bias) {
-      v += *(const f32x4*)(a.bias + n);
     }
+    const int oc = out_col(a, n);  // output column
     const bool to_vt = a.vt && n >= a.vt_from;
     if (oc >= a.n_out && !to_vt) return;
-    if (a.rowvec) v += *(const f32x4*)(a.rowvec + r.rv_off + n);
+    if (a.rowvec) v += in.rv;
     if (flags & UPK_F_SILU) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = upk_silu(v[k]);
@@ -132,9 +165,8 @@ struct Epi {
       return;
     }
     if (a.res) {
-      const f16x4 rr = *(const f16x4*)(a.res + r.res_off + oc);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] += (float)rr[k];
+      for (int k = 0; k < 4; ++k) v[k] += (float)in.res[k];
     }
     if (flags & UPK_F_OUT_NCHW_F32) {
       float* yo = (float*)a.y + r.nchw_off;
@@ -162,6 +194,156 @@ struct Epi {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (oc + k < a.n_out) yo[k] = (f16)v[k];
+      }
+    }
+  }
+
+  // The common epilogues as STRAIGHT-LINE code.  Every launch starts with a cold instruction cache,
+  // and the general `store` above is a chain of taken branches over the GEGLU / SiLU / V^T / NCHW
+  // blocks: ~8 jumps to cold lines per fragment, 5-8k cycles for a 4..7-fragment tile (s_memtime
+  // stamps, scripts/timeline.py) against ~1k for the stores themselves.
+  //   plain: fp32 acc + bias + timestep row vector + residual -> fp16 NHWC; absent operands point at
+  //          the zero page instead of being branched around;
+  //   geglu: (acc_v + b_v) * gelu(acc_g + b_g) -> fp16.
+  static __device__ __forceinline__ bool plain(const IgemmArgs& a) {
+    return !(a.flags & (UPK_F_GEGLU | UPK_F_SILU | UPK_F_OUT_F32 | UPK_F_OUT_NCHW_F32)) && !a.vt && !(a.n_out & 3);
+  }
+  static __device__ __forceinline__ bool plain_geglu(const IgemmArgs& a) {
+    return (a.flags & (UPK_F_GEGLU | UPK_F_SILU | UPK_F_OUT_F32 | UPK_F_OUT_NCHW_F32)) == UPK_F_GEGLU && !a.vt &&
+           !a.rowvec && !a.res && !(a.n_out & 3);
+  }
+  struct Plain {
+    const float* bias;
+    const float* rvp;
+    const f16* resp;
+    unsigned has_b, has_rv, has_res;
+    int st, hw;
+    __device__ __forceinline__ Plain(const IgemmArgs& a) {
+      bias = a.bias ? a.bias : (const float*)a.zero;
+      rvp = a.rowvec ? a.rowvec : (const float*)a.zero;
+      resp = a.res ? a.res : a.zero;
+      has_b = a.bias ? ~0u : 0u;
+      has_rv = a.rowvec ? ~0u : 0u;
+      has_res = a.res ? ~0u : 0u;
+      st = (a.rowvec && a.step) ? *a.step : 0;
+      hw = a.Ho * a.Wo;
+    }
+    __device__ __forceinline__ f32x4 bias4(const IgemmArgs& a, int n) const {
+      return *(const f32x4*)(bias + ((n < a.npad ? (unsigned)n : 0u) & has_b));
+    }
+    // row part: offsets of row m (clamped to a valid row; the store is predicated on m < M)
+    struct Row {
+      bool ok;
+      unsigned rv_off, res_off, y_off;
+    };
+    __device__ __forceinline__ Row row(const IgemmArgs& a, int m) const {
+      Row r;
+      r.ok = m < a.M;
+      const unsigned mm = r.ok ? (unsigned)m : 0u;
+      r.rv_off = has_rv ? (unsigned)(st * a.rv_ss + (int)(mm / (unsigned)hw) * a.rv_bs) : 0u;
+      r.res_off = (mm * (unsigned)a.ldr) & has_res;
+      r.y_off = mm * (unsigned)a.ldy;
+      return r;
+    }
+    __device__ __forceinline__ f32x4 rv4(const IgemmArgs& a, const Row& r, int n) const {
+      return *(const f32x4*)(rvp + ((r.rv_off + (n < a.n_out ? (unsigned)n : 0u)) & has_rv));
+    }
+    __device__ __forceinline__ f16x4 res4(const IgemmArgs& a, const Row& r, int n) const {
+      return *(const f16x4*)(resp + r.res_off + ((n < a.n_out ? (unsigned)n : 0u) & has_res));
+    }
+    static __device__ __forceinline__ void put(const IgemmArgs& a, const Row& r, int n, f32x4 v, const f16x4 rr) {
+      f16x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = (f16)(v[k] + (float)rr[k]);
+      if (r.ok && n < a.n_out) *(f16x4*)((f16*)a.y + r.y_off + n) = o;
+    }
+  };
+
+  template <int MI, int NI>
+  static __device__ __forceinline__ void tile_plain(const IgemmArgs& a, int mw, int nw, int lc, int lg,
+                                                    const f32x4 (&acc)[MI][NI]) {
+    const Plain P(a);
+    f32x4 bv[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) bv[j] = P.bias4(a, nw + j * 16 + lg * 4);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const Plain::Row r = P.row(a, mw + i * 16 + lc);
+      f32x4 rv[NI];
+      f16x4 rr[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        rv[j] = P.rv4(a, r, nw + j * 16 + lg * 4);
+        rr[j] = P.res4(a, r, nw + j * 16 + lg * 4);
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) Plain::put(a, r, nw + j * 16 + lg * 4, acc[i][j] + bv[j] + rv[j], rr[j]);
+    }
+  }
+
+  template <int MI, int NI>
+  static __device__ __forceinline__ void tile_geglu(const IgemmArgs& a, int mw, int nw, int lc, int lg,
+                                                    const f32x4 (&acc)[MI][NI]) {
+    static_assert(NI % 4 == 0, "GEGLU tiles are [32 value | 32 gate] column blocks");
+    const float* bias = a.bias ? a.bias : (const float*)a.zero;
+    const unsigned has_b = a.bias ? ~0u : 0u;
+    f32x4 bv[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = nw + j * 16 + lg * 4;
+      bv[j] = *(const f32x4*)(bias + ((n < a.npad ? (unsigned)n : 0u) & has_b));
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = mw + i * 16 + lc;
+      const bool ok = m < a.M;
+      f16* yrow = (f16*)a.y + (ok ? (unsigned)m : 0u) * (unsigned)a.ldy;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        if (j & 2) continue;  // gate fragments are consumed by their value partner j - 2
+        const int n = nw + j * 16 + lg * 4;
+        const int oc = (n >> 6) * 32 + (n & 31);
+        const f32x4 v = acc[i][j] + bv[j];
+        const f32x4 g = acc[i][j + 2 < NI ? j + 2 : j] + bv[j + 2 < NI ? j + 2 : j];
+        f16x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (f16)(v[k] * upk_gelu(g[k]));
+        if (ok && n < a.npad && oc < a.n_out) *(f16x4*)(yrow + oc) = o;
+      }
+    }
+  }
+
+  // Epilogue of a wave's MI x NI register tile at (mw, nw).
+  template <int MI, int NI>
+  static __device__ __forceinline__ void tile(const IgemmArgs& a, int mw, int nw, int lc, int lg,
+                                              const f32x4 (&acc)[MI][NI]) {
+    if (plain(a)) {
+      tile_plain<MI, NI>(a, mw, nw, lc, lg, acc);
+      return;
+    }
+    if constexpr (NI % 4 == 0) {
+      if (plain_geglu(a)) {
+        tile_geglu<MI, NI>(a, mw, nw, lc, lg, acc);
+        return;
+      }
+    }
+    const bool geglu = a.flags & UPK_F_GEGLU;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const RowCtx rc = row(a, mw + i * 16 + lc);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = nw + j * 16 + lg * 4;
+        if (n >= a.npad) continue;
+        if (geglu) {
+          if constexpr (NI % 4 == 0) {
+            if ((j & 2) == 0) store(a, rc, n, acc[i][j], acc[i][j + 2 < NI ? j + 2 : j], bias4(a, n), bias4(a, n + 32),
+                                    fetch(a, rc, n));
+          }
+        } else {
+          const f32x4 b = bias4(a, n);
+          store(a, rc, n, acc[i][j], acc[i][j], b, b, fetch(a, rc, n));
+        }
       }
     }
   }
@@ -392,22 +574,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
     }
     return;
   }
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const RowCtx rc = Epi::row(a, mw + i * 16 + lc);
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int n = nw + j * 16 + lg * 4;
-      if (n >= a.npad) continue;
-      if (a.flags & UPK_F_GEGLU) {
-        if constexpr (NI % 4 == 0) {
-          if ((j & 2) == 0) Epi::store(a, rc, n, acc[i][j], acc[i][j + 2 < NI ? j + 2 : j]);
-        }
-      } else {
-        Epi::store(a, rc, n, acc[i][j], acc[i][j]);
-      }
-    }
-  }
+  Epi::tile<MI, NI>(a, mw, nw, lc, lg, acc);
 }
 
 
@@ -451,6 +618,14 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
 
   __shared__ __attribute__((aligned(16))) f16 smem[NBUF * STAGE + DUMP];
 
+  if (a.flags & ABL_EMPTY) return;
+  const bool tl = (a.flags & ABL_TIMELINE) && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && blockIdx.z == 0;
+  unsigned long long* tlp = a.dbg + (blockIdx.x == 0 ? 0 : 32);
+#ifdef UPK_TIMELINE
+#define STAMP(i) do { if (tl && (threadIdx.x & 63) == 0) tlp[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i) do { (void)tl; (void)tlp; } while (0)
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -466,6 +641,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
   if (wave >= 4) {
     // ================================ loader ================================
     const int lw = wave - 4;
+    if (lw == 0) STAMP(8);
     const int r16 = lane >> 2;                                  // row inside a 16-row group
     const int chd = (lane & 3) ^ ((-(lane >> 4)) & 3);          // source chunk of this lane (swizzle)
     const f16* zsrc = a.zero + (lane & 3) * 8;
@@ -574,8 +750,11 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
       else wait_vmcnt<0>();
     };
     int issued = 0;
+    if (lw == 0) STAMP(9);
     for (; issued < D && issued < nstages; ++issued) issue_stage(issued % NBUF);
+    if (lw == 0) STAMP(10);
     wait_oldest(issued);  // stage 0 landed
+    if (lw == 0) STAMP(11);
     __builtin_amdgcn_s_barrier();
     for (int t = 0; t < nstages; ++t) {
       // slot (t + D) % NBUF held stage t - 1: its readers passed the barrier that ended iteration t-1
@@ -587,10 +766,12 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
       if (outstanding > 0) wait_oldest(outstanding);
       __builtin_amdgcn_s_barrier();
     }
+    if (lw == 0) STAMP(12);
     return;
   }
 
   // ================================ consumers ================================
+  if (wave == 0) STAMP(0);
   const int wm = KSPLIT ? 0 : wave / WN;
   const int wn = KSPLIT ? 0 : wave - wm * WN;
   const int lg = lane >> 4;
@@ -605,7 +786,9 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
   const int b_base = (BM + wn * (NI * 16)) * 32 + frag_off;
 
   __builtin_amdgcn_s_barrier();  // stage 0 is in LDS
+  if (wave == 0) STAMP(1);
   for (int t = 0; t < nstages; ++t) {
+    if (wave == 0 && t == 1) STAMP(2);
     const f16* slot = smem + (t % NBUF) * STAGE;
 #pragma unroll
     for (int s0 = 0; s0 < (KSPLIT ? KS / 4 : KS); ++s0) {
@@ -634,6 +817,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // our LDS reads are done before the slot is reused
     __builtin_amdgcn_s_barrier();
   }
+  if (wave == 0) STAMP(3);
 
   if constexpr (KSPLIT) {
     // ---- sum the 4 K-slices through LDS (the ring is free: all consumers passed the last barrier)
@@ -653,21 +837,68 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
       return v;
     };
     float* slab = a.partial ? a.partial + (long)blockIdx.z * a.M * a.npad : nullptr;
-    for (int f = wave; f < NF; f += 4) {  // fragment f = (i, j) is finished by wave f % 4
+    if (slab) {
+      for (int f = wave; f < NF; f += 4) {  // fragment f = (i, j) is finished by wave f % 4
+        const int i = f / NI, j = f - i * NI;
+        const int m = m0 + i * 16 + lc;
+        const int n = n0 + j * 16 + lg * 4;
+        if (n < a.npad && m < a.M) *(f32x4*)(slab + (unsigned)m * (unsigned)a.npad + n) = frag_sum(f);
+      }
+      return;
+    }
+    // this wave's fragments f = wave + 4q
+    constexpr int FW = (NF + 3) / 4;
+    if (Epi::plain(a)) {  // straight-line common case (see Epi::Plain)
+      const Epi::Plain P(a);
+      Epi::Plain::Row rows[FW];
+      f32x4 bvs[FW], rvs[FW];
+      f16x4 rrs[FW];
+#pragma unroll
+      for (int q = 0; q < FW; ++q) {
+        const int f = wave + 4 * q;
+        const int i = f / NI, j = f - i * NI;
+        const int n = n0 + j * 16 + lg * 4;
+        rows[q] = P.row(a, f < NF ? m0 + i * 16 + lc : a.M);
+        bvs[q] = P.bias4(a, n);
+        rvs[q] = P.rv4(a, rows[q], n);
+        rrs[q] = P.res4(a, rows[q], n);
+      }
+#pragma unroll
+      for (int q = 0; q < FW; ++q) {
+        const int f = wave + 4 * q;
+        if (f >= NF) continue;
+        const int j = f - (f / NI) * NI;
+        Epi::Plain::put(a, rows[q], n0 + j * 16 + lg * 4, frag_sum(f) + bvs[q] + rvs[q], rrs[q]);
+      }
+      return;
+    }
+    const bool geglu = a.flags & UPK_F_GEGLU;
+    RowCtx rcs[FW];
+    Epi::In ins[FW];
+    f32x4 bvs[FW], bgs[FW];
+#pragma unroll
+    for (int q = 0; q < FW; ++q) {
+      const int f = wave + 4 * q;
       const int i = f / NI, j = f - i * NI;
-      const int m = m0 + i * 16 + lc;
+      const int n = n0 + j * 16 + lg * 4;
+      const bool live = f < NF && !(geglu && (j & 2));
+      rcs[q] = Epi::row(a, live ? m0 + i * 16 + lc : a.M);
+      bvs[q] = Epi::bias4(a, live ? n : a.npad);
+      bgs[q] = Epi::bias4(a, live && geglu ? n + 32 : a.npad);
+      ins[q] = Epi::fetch(a, rcs[q], n);
+    }
+#pragma unroll
+    for (int q = 0; q < FW; ++q) {
+      const int f = wave + 4 * q;
+      if (f >= NF) continue;
+      const int i = f / NI, j = f - i * NI;
       const int n = n0 + j * 16 + lg * 4;
       if (n >= a.npad) continue;
-      if (slab) {
-        if (m < a.M) *(f32x4*)(slab + (unsigned)m * (unsigned)a.npad + n) = frag_sum(f);
-        continue;
-      }
-      const RowCtx rc = Epi::row(a, m);
-      if (a.flags & UPK_F_GEGLU) {
-        if ((j & 2) == 0 && j + 2 < NI) Epi::store(a, rc, n, frag_sum(f), frag_sum(f + 2));
+      if (geglu) {
+        if ((j & 2) == 0 && j + 2 < NI) Epi::store(a, rcs[q], n, frag_sum(f), frag_sum(f + 2), bvs[q], bgs[q], ins[q]);
       } else {
         const f32x4 v = frag_sum(f);
-        Epi::store(a, rc, n, v, v);
+        Epi::store(a, rcs[q], n, v, v, bvs[q], bvs[q], ins[q]);
       }
     }
     return;
@@ -698,22 +929,14 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
     }
     return;
   }
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const RowCtx rc = Epi::row(a, mw + i * 16 + lc);
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int n = nw + j * 16 + lg * 4;
-      if (n >= a.npad) continue;
-      if (a.flags & UPK_F_GEGLU) {
-        if constexpr (NI % 4 == 0) {
-          if ((j & 2) == 0) Epi::store(a, rc, n, acc[i][j], acc[i][j + 2 < NI ? j + 2 : j]);
-        }
-      } else {
-        Epi::store(a, rc, n, acc[i][j], acc[i][j]);
-      }
-    }
+  Epi::tile<MI, NI>(a, mw, nw, lc, lg, acc);
+#ifdef UPK_TIMELINE
+  if (wave == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(4);
   }
+#endif
+#undef STAMP
 }
 
 // Split-K second pass: sums the slabs in fixed order (deterministic) and runs the epilogue.
@@ -738,7 +961,9 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmArgs a, in
   }
   IgemmArgs b = a;
   b.partial = nullptr;
-  Epi::store(b, Epi::row(b, m), n, v, g);
+  const RowCtx rc = Epi::row(b, m);
+  Epi::store(b, rc, n, v, g, Epi::bias4(b, n), Epi::bias4(b, (a.flags & UPK_F_GEGLU) ? n + 32 : a.npad),
+             Epi::fetch(b, rc, n));
 }
 
 struct CfgInfo {
@@ -905,7 +1130,8 @@ extern "C" int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_str
   a.cpt = (a.c1 + a.c2) / 32;
   a.nchunks = a.ks * a.ks * a.cpt;
   a.flags = flags;
-  if (const char* ab = getenv("UPK_ABLATE")) a.flags |= (int)strtol(ab, nullptr, 0) & 0xF0000;
+  if (const char* ab = getenv("UPK_ABLATE")) a.flags |= (int)strtol(ab, nullptr, 0) & 0x3F0000;
+  a.dbg = (unsigned long long*)((char*)ctx->ws + ctx->ws_bytes - 4096);
 
   // ---- choose config + split-K ----
   int best = -1, best_sk = 1;
