@@ -31,6 +31,12 @@ from collections import Counter
 cnt = Counter(pl.body.cls)
 full = timed(())
 print("full forward %.3f ms  launches by class: %s" % (full, dict(cnt)))
+for c in [int(v) for v in os.environ.get("FORCE_CFGS", "").split(",") if v]:
+    # one igemm binary for every launch (split-K by the cost model): code-locality experiment
+    ctx.conv_override(c, 0)
+    print("  every igemm forced to cfg %s: %.3f ms" % (ctx.lib.upk_conv_config_name(c).decode(), timed(())))
+    ctx.conv_override(-1, 0)
+if os.environ.get("FORCE_ONLY"): sys.exit(0)
 for cls in sorted(cnt):
     t = timed((cls,))
     print("  without %-12s %.3f ms  -> class costs %.3f ms (%d launches, %.1f us each)" % (cls, t, full - t, cnt[cls], (full - t) / cnt[cls] * 1e3))

@@ -1,6 +1,7 @@
 """In-kernel timeline of one WS igemm launch (UPK_ABLATE=0x200000 stamps; dev tool).
    python scripts/timeline.py B H W cin cout ks cfg sk"""
 import os, sys, math, ctypes
+os.environ["UPK_CXXFLAGS"] = "-DUPK_TIMELINE"  # needs a stamp-enabled build: rm upgpt_amd/libupk.so first
 os.environ["UPK_ABLATE"] = hex(int(os.environ.get("UPK_ABLATE", "0"), 0) | 0x200000)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,6 +23,7 @@ d.tune_cfg = cfg + 1; d.tune_splitk = sk
 flush = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
 ws = ctx.workspace  # torch uint8 tensor
 names = {0: "c.entry", 1: "c.stage0 ready", 2: "c.stage1 start", 3: "c.loop end", 4: "c.stores done",
+
          8: "l.entry", 9: "l.setup done", 10: "l.prologue issued", 11: "l.stage0 landed", 12: "l.loop end"}
 for trial in range(4):
     if trial >= 2:

@@ -1167,6 +1167,21 @@ extern "C" int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_str
   const int zdim = cdiv(a.nchunks, a.chunks_per_split);
   a.partial = (zdim > 1) ? (float*)ctx->ws : nullptr;
 
+#ifdef UPK_TIMELINE
+  {  // dev: UPK_TL_TARGET=n stamps only the n-th conv launch of the process (e.g. one launch inside the forward graph)
+    static int launch_no = 0;
+    static const char* tgt = getenv("UPK_TL_TARGET");
+    if (tgt) {
+      a.flags &= ~ABL_TIMELINE;
+      if (launch_no == atoi(tgt)) {
+        a.flags |= ABL_TIMELINE;
+        fprintf(stderr, "[timeline] launch %d: M=%d npad=%d nchunks=%d ks=%d cfg=%s(%d) splitk=%d flags=%x res=%d rowvec=%d\n", launch_no,
+                a.M, a.npad, a.nchunks, a.ks, kCfgs[best].name, best, zdim, flags, a.res != nullptr, a.rowvec != nullptr);
+      }
+      ++launch_no;
+    }
+  }
+#endif
   upk_prof_scope prof(ctx, UPK_CLS_IGEMM, stream);
   dim3 grid(a.tiles_m * a.tiles_n, 1, zdim);
   hipLaunchKernelGGL(c.fn, grid, dim3(c.nbuf ? 512 : c.wm * c.wn * 64), 0, stream, a);
