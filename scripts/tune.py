@@ -13,6 +13,10 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["UPGPT_AUTOTUNE"] = "1"
+# time every candidate with flushed caches (the in-forward condition), unless UPK_TUNE_WARM=1
+if os.environ.get("UPK_TUNE_WARM", "0") != "1":
+    os.environ.setdefault("UPK_TUNE_COLD", "1")
+os.environ.setdefault("UPGPT_TUNE_REPS", "8")
 import upgpt_amd  # noqa: E402
 from upgpt_amd import synth  # noqa: E402
 from upgpt_amd.engine import TUNE_CACHE  # noqa: E402

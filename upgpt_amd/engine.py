@@ -62,7 +62,7 @@ class TuneCache:
         self.dirty = False
 
 
-TUNE_CACHE = TuneCache()
+TUNE_CACHE = TuneCache(os.environ.get("UPGPT_TUNE_FILE") or None)
 
 
 def head_pad(d):
@@ -194,7 +194,7 @@ class Emitter:
         self.bufs = []
         self.convs = []  # (ConvDesc, shape-signature) of every emitted conv, for autotuning
 
-    def apply_tuning(self, cache=None, tune_missing=False, reps=5):
+    def apply_tuning(self, cache=None, tune_missing=False, reps=None):
         """Pins each conv launch to the (tile config, split-K) stored in the tuning cache;
         with tune_missing=True unknown shapes are timed on the device first
         (upk_conv_autotune) and added to the cache.  Returns (#hits, #tuned, #missing)."""
@@ -203,7 +203,7 @@ class Emitter:
         for d, key in self.convs:
             ent = cache.get(key)
             if ent is None and tune_missing:
-                cfg, sk, best_us, dflt_us = self.ctx.conv_autotune(d, reps)
+                cfg, sk, best_us, dflt_us = self.ctx.conv_autotune(d, reps or int(os.environ.get("UPGPT_TUNE_REPS", "5")))
                 ent = cache.put(key, cfg, sk, best_us, dflt_us)
                 tuned += 1
             elif ent is not None:
