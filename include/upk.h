@@ -121,6 +121,15 @@ typedef struct upk_conv_desc {
   /* tile configuration = tune_cfg - 1 and split-K factor chosen by upk_conv_autotune
    * (0 = let the built-in cost model decide). */
   int32_t tune_cfg, tune_splitk;
+  /* LayerNorm folded into a Linear (BasicTransformerBlock norm1/2/3 -> to_q|k|v / to_q / GEGLU proj,
+   * attention.py:203-215): with ln_colsum != NULL the rows of x1 are the UN-normalised residual stream
+   * (ksize 1, c2 == 0), the packed weight must be W * gamma (column scaled), bias must be b + W @ beta,
+   * ln_colsum[n] = sum_k fp16(W*gamma)[n, k] in PACKED row order (fp32 [n_pad]); the kernel takes each
+   * row's mean / variance over its first ln_dim channels (fp32, from the fp16 tiles it stages anyway)
+   * and finishes  y = rstd * (x @ W'^T - mean * colsum) + bias'  before the usual epilogue. */
+  const float* ln_colsum;
+  float ln_eps;
+  int32_t ln_dim;
 } upk_conv_desc;
 
 /* Replaces F.conv2d (3x3 s1/s2 p1, 1x1) / F.linear call sites:

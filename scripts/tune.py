@@ -46,10 +46,15 @@ for kind in kinds:
     ntok = 86 if kind == "upscale" else 87
     shapes = [(8, 32, 32, 50), (8, 32, 24, 50)] if kind == "bbox" else [(4, 64, 64, 50)]
     for (B, H, W, S) in shapes:
-        t0 = time.time()
-        pl = unet.plan(B, H, W, ntok, S, "sampler")
-        summarize("%s unet sampler B=%d %dx%d (%.0fs)" % (kind, B, H, W, time.time() - t0), pl)
-        TUNE_CACHE.save(out)
+        for fold in ("1", "0"):  # LayerNorm folded into its consumer GEMM / separate: both get measured
+            os.environ["UPGPT_LN_FOLD"] = fold
+            unet._plans.clear()
+            t0 = time.time()
+            pl = unet.plan(B, H, W, ntok, S, "sampler")
+            summarize("%s unet sampler B=%d %dx%d ln_fold=%s (%.0fs)" % (kind, B, H, W, fold, time.time() - t0), pl)
+            TUNE_CACHE.save(out)
+        os.environ.pop("UPGPT_LN_FOLD")
+        unet._plans.clear()
         t0 = time.time()
         vp = model.first_stage_model._decode_plan(B, H, W, 0.18215)
         summarize("%s vae decode B=%d %dx%d (%.0fs)" % (kind, B, H, W, time.time() - t0), vp)

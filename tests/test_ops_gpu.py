@@ -204,6 +204,64 @@ def test_gemm_geglu(ctx, M, d):
     ctx.conv_override(-1, 0)
 
 
+@pytest.mark.parametrize("M,d,N,geglu", [(8192, 224, 768, False), (600, 448, 512, False), (96, 896, 896, False),
+                                          (512, 224, 1792, True)])
+def test_gemm_with_folded_layernorm(ctx, M, d, N, geglu):
+    """LayerNorm folded into its consumer Linear (upk_conv_desc.ln_colsum): rows are the raw residual
+    stream (offset mean, per-row scale), weights W*gamma, bias b + W@beta (attention.py:203-215)."""
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = (torch.randn(M, d, generator=g) * (0.5 + 3 * torch.rand(M, 1, generator=g)) + 4 * torch.randn(M, 1, generator=g))
+    x = x.to(DEV).half()
+    gamma = 1 + 0.2 * rnd(d, seed=2)
+    beta = 0.1 * rnd(d, seed=3)
+    w = rnd(N, d, scale=1 / math.sqrt(d), seed=4)
+    b = rnd(N, scale=0.1, seed=5)
+    h = F.layer_norm(x.float(), (d,), gamma, beta, 1e-5) @ w.t() + b
+    if geglu:
+        inner = N // 2
+        ref = h[:, :inner] * F.gelu(h[:, inner:])
+        rm = geglu_row_map(inner).to(DEV)
+    else:
+        ref, rm = h, None
+    wf = (w * gamma[None, :]).contiguous()
+    wp, n_pad = ctx.pack_weight(wf, row_map=rm)
+    bf = b + w @ beta
+    u = wf.half().float().sum(dim=1)
+    if rm is not None:
+        bf, u = bf[rm.long()], u[rm.long()]
+    bp = torch.zeros(n_pad, device=DEV); bp[: bf.numel()] = bf
+    up = torch.zeros(n_pad, device=DEV); up[: u.numel()] = u
+    n_out = N // 2 if geglu else N
+    y = torch.zeros(M, n_out, device=DEV, dtype=torch.float16)
+    dsc = L.ConvDesc()
+    dsc.x1 = x.data_ptr(); dsc.c1 = d; dsc.ld1 = d; dsc.batch = 1; dsc.in_h = M; dsc.in_w = 1
+    dsc.ksize = 1; dsc.stride = 1; dsc.w_packed = wp.data_ptr(); dsc.n_out = n_out; dsc.n_pad = n_pad
+    dsc.bias = bp.data_ptr(); dsc.y = y.data_ptr(); dsc.ldy = n_out; dsc.flags = L.F_GEGLU if geglu else 0
+    dsc.ln_colsum = up.data_ptr(); dsc.ln_eps = 1e-5; dsc.ln_dim = d
+    ctx.conv(dsc)
+    torch.cuda.synchronize()
+    check(y, ref, tol=4e-3)
+    # every configuration that supports the fold agrees; the others are refused, never silently wrong
+    ok = 0
+    for cfg in range(ctx.lib.upk_conv_num_configs()):
+        ctx.conv_override(cfg, 1)
+        y.zero_()
+        try:
+            ctx.conv(dsc)
+        except L.UpkError:
+            continue
+        finally:
+            ctx.conv_override(-1, 0)
+        torch.cuda.synchronize()
+        check(y, ref, tol=4e-3)
+        ok += 1
+    assert ok >= 4
+    ctx.conv_override(-1, 2)
+    with pytest.raises(L.UpkError):
+        ctx.conv(dsc)
+    ctx.conv_override(-1, 0)
+
+
 def test_qkv_gemm_with_transposed_v(ctx):
     """Fused q|k|v projection: q,k token-major, v written as V^T [B, heads, dpad, vt_ld];
     head dim 28 padded to 32 by the packing row map."""

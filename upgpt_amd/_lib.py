@@ -51,6 +51,7 @@ class ConvDesc(C.Structure):
         ("vt", C.c_void_p), ("vt_from", C.c_int32), ("vt_heads", C.c_int32), ("vt_dhead", C.c_int32),
         ("vt_ld", C.c_int32), ("vt_tokens", C.c_int32), ("flags", C.c_int32),
         ("tune_cfg", C.c_int32), ("tune_splitk", C.c_int32),
+        ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_dim", C.c_int32),
     ]
 
 

@@ -59,6 +59,9 @@ struct IgemmArgs {
   int ks, stride, pad_lo, ups;
   int linear;      // ks == 1 && stride == 1 && !ups: rows are addressed directly
   unsigned long long* dbg;  // ABL_TIMELINE stamps
+  const float* ln_u;  // folded LayerNorm: column sums of the packed (gamma-scaled) weight, or nullptr
+  float ln_eps;
+  float ln_inv_dim;
   int cpt;         // 32-wide chunks per tap = (c1+c2)/32
   int nchunks;     // ks*ks*cpt
   int chunks_per_split;
@@ -785,6 +788,13 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
   const int a_base = wm * (MI * 16) * 32 + frag_off;
   const int b_base = (BM + wn * (NI * 16)) * 32 + frag_off;
 
+  // folded LayerNorm (M x N split only): per-row sum / sum of squares of the A fragments this wave
+  // reads anyway; lane (lc, lg) sees row lc, k-slice lg of every chunk
+  const bool ln = a.ln_u != nullptr;
+  float ln_s1[MI], ln_s2[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) ln_s1[i] = ln_s2[i] = 0.f;
+
   __builtin_amdgcn_s_barrier();  // stage 0 is in LDS
   if (wave == 0) STAMP(1);
   for (int t = 0; t < nstages; ++t) {
@@ -807,6 +817,20 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
 #pragma unroll
           for (int j = 0; j < NI; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        if constexpr (!KSPLIT) {
+          if (ln) {  // VALU work beside the MFMAs above
+            const f16x2 one2 = {(f16)1.f, (f16)1.f};
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+              for (int h = 0; h < 4; ++h) {
+                const f16x2 xx = {fa[i][2 * h], fa[i][2 * h + 1]};
+                ln_s1[i] = __builtin_amdgcn_fdot2(xx, one2, ln_s1[i], false);
+                ln_s2[i] = __builtin_amdgcn_fdot2(xx, xx, ln_s2[i], false);
+              }
+            }
+          }
+        }
       } else {
 #pragma unroll
         for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(fa[i]));
@@ -905,6 +929,27 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
   }
   const int mw = m0 + wm * (MI * 16);
   const int nw = n0 + wn * (NI * 16);
+  if (ln) {  // y = rstd * (acc - mean * colsum): the lane's accumulator row is the row it has the statistics of
+    f32x4 u[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = nw + j * 16 + lg * 4;
+      u[j] = n < a.npad ? *(const f32x4*)(a.ln_u + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      float s1 = ln_s1[i], s2 = ln_s2[i];
+      s1 += __shfl_xor(s1, 16);
+      s2 += __shfl_xor(s2, 16);
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      const float mean = s1 * a.ln_inv_dim;
+      const float var = fmaxf(s2 * a.ln_inv_dim - mean * mean, 0.f);
+      const float rstd = rsqrtf(var + a.ln_eps);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = (acc[i][j] - mean * u[j]) * rstd;
+    }
+  }
   if (a.flags & ABL_NOEPI) {
     float t = 0.f;
 #pragma unroll
@@ -1127,6 +1172,11 @@ extern "C" int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_str
   a.M = a.B * a.Ho * a.Wo;
   if (a.M <= 0) return upk_fail(ctx, UPK_EINVAL, "conv: empty output");
   a.linear = (a.ks == 1 && a.stride == 1 && !a.ups) ? 1 : 0;
+  a.ln_u = d->ln_colsum;
+  a.ln_eps = d->ln_eps;
+  a.ln_inv_dim = d->ln_dim > 0 ? 1.0f / (float)d->ln_dim : 0.f;
+  if (a.ln_u && (!a.linear || d->c2 != 0 || d->ln_dim <= 0 || d->ln_dim > d->c1))
+    return upk_fail(ctx, UPK_EINVAL, "conv: folded LayerNorm needs a 1x1 stride-1 single-source launch, 0 < ln_dim <= c1");
   a.cpt = (a.c1 + a.c2) / 32;
   a.nchunks = a.ks * a.ks * a.cpt;
   a.flags = flags;
@@ -1142,8 +1192,11 @@ extern "C" int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_str
   const int want_sk = ctx->splitk_override > 0 ? ctx->splitk_override : (d->tune_splitk > 0 ? d->tune_splitk : 0);
   for (int c = 0; c < kNumCfgs; ++c) {
     if (want_cfg >= 0 && c != want_cfg) continue;
+    // folded LayerNorm: row statistics come from the M x N-split wave-specialised kernels, whole K in one block
+    if (a.ln_u && !(kCfgs[c].nbuf && kCfgs[c].wm * kCfgs[c].wn > 1)) continue;
     for (int sk : sk_cands) {
       if (want_sk > 0 && sk != want_sk) continue;
+      if (a.ln_u && sk > 1) continue;
       if (sk > 1 && (slab * sk > ctx->ws_bytes || a.nchunks / sk < 4)) continue;
       const double t = estimate(kCfgs[c], a.M, a.npad, a.nchunks, sk, ctx->num_cus, geglu);
       if (t < best_t) {

@@ -63,6 +63,7 @@ class TuneCache:
 
 
 TUNE_CACHE = TuneCache(os.environ.get("UPGPT_TUNE_FILE") or None)
+LN_LAUNCH_US = 3.0  # what a separate LayerNorm launch costs inside the replayed forward (class ablation: 3.8)
 
 
 def head_pad(d):
@@ -90,7 +91,7 @@ class Act:
 
 class PW:
     """A packed weight: fp16 tiles + fp32 bias in packed row order."""
-    __slots__ = ("w", "n_pad", "bias", "n_out", "k_packed", "ksize", "n_real", "k_real")
+    __slots__ = ("w", "n_pad", "bias", "n_out", "k_packed", "ksize", "n_real", "k_real", "ln_colsum")
 
 
 class Packer:
@@ -102,14 +103,22 @@ class Packer:
     def _maps(self, m):
         return None if m is None else torch.as_tensor(m, dtype=torch.int32, device=self.dev).contiguous()
 
-    def pack(self, names, row_map=None, col_map=None, cin_packed=None, bias=True, n_out=None):
-        """`names`: one weight name or a list whose rows are concatenated (fused q|k|v)."""
+    def pack(self, names, row_map=None, col_map=None, cin_packed=None, bias=True, n_out=None, ln=None):
+        """`names`: one weight name or a list whose rows are concatenated (fused q|k|v).
+        `ln`: name of a LayerNorm whose affine is folded into this Linear (include/upk.h ln_colsum):
+        W' = W * gamma, bias' = bias + W @ beta, plus the column sums of the fp16-rounded W'."""
         if isinstance(names, str):
             names = [names]
         ws = [self.get(n + ".weight") for n in names]
         w = ws[0] if len(ws) == 1 else torch.cat([x.reshape(x.shape[0], -1) for x in ws], 0).reshape(
             -1, *ws[0].shape[1:])
         w = w.contiguous().float()
+        ln_bias = None
+        if ln is not None:
+            assert w.dim() == 2 and col_map is None
+            gamma, beta = self.get(ln + ".weight").float(), self.get(ln + ".bias").float()
+            ln_bias = w @ beta
+            w = (w * gamma[None, :]).contiguous()
         rm, cm = self._maps(row_map), self._maps(col_map)
         p = PW()
         p.w, p.n_pad = self.ctx.pack_weight(w, row_map=rm, col_map=cm, cin_packed=cin_packed)
@@ -120,17 +129,26 @@ class Packer:
         p.n_out = n_rows if n_out is None else n_out
         p.n_real = w.shape[0] if rm is None else int((rm >= 0).sum().item())
         p.k_real = (cin if cm is None else int((cm >= 0).sum().item())) * p.ksize * p.ksize
+        def rows_packed(vec):  # per-output-row vector -> packed row order, zero padded to n_pad
+            out = torch.zeros(p.n_pad, dtype=torch.float32, device=self.dev)
+            if rm is None:
+                out[: vec.numel()] = vec
+            else:
+                idx = rm.long()
+                out[: idx.numel()] = torch.where(idx >= 0, vec[idx.clamp(min=0)], torch.zeros((), device=self.dev))
+            return out
+
         p.bias = None
+        p.ln_colsum = None
+        b = None
         if bias:
             bs = [self.get(n + ".bias") for n in names]
             b = (bs[0] if len(bs) == 1 else torch.cat(bs, 0)).float()
-            bp = torch.zeros(p.n_pad, dtype=torch.float32, device=self.dev)
-            if rm is None:
-                bp[: b.numel()] = b
-            else:
-                idx = rm.long()
-                bp[: idx.numel()] = torch.where(idx >= 0, b[idx.clamp(min=0)], torch.zeros((), device=self.dev))
-            p.bias = bp
+        if ln_bias is not None:
+            b = ln_bias if b is None else b + ln_bias
+            p.ln_colsum = rows_packed(w.half().float().sum(dim=1))
+        if b is not None:
+            p.bias = rows_packed(b)
         return p
 
     def vec(self, name):
@@ -223,8 +241,34 @@ class Emitter:
         if rc != 0:
             self.ctx._chk(rc)
 
+    @staticmethod
+    def conv_key(M, n_pad, c1, c2, ks, stride, flags, has_res, has_rowvec, has_vt, ln):
+        """Shape signature of one conv/GEMM launch = key of the tuning cache."""
+        return "M%d_N%d_C%d+%d_k%ds%d_f%x_r%d%d%d%s" % (M, n_pad, c1, c2, ks, stride, flags, has_res, has_rowvec,
+                                                       has_vt, "_ln" if ln else "")
+
+    def ln_linear(self, P, x, name, norm, flags=0, **kw):
+        """LayerNorm `norm` followed by the Linear `name`: either one launch with the norm folded into the
+        GEMM (weights packed as name + "_ln") or LayerNorm launch + plain GEMM, whichever the tuning
+        cache says is faster for this shape (the fold costs VALU work in the GEMM's MFMA waves and rules
+        out the classic / K-split tile configurations; a LayerNorm launch costs ~3.8 us under replay).
+        UPGPT_LN_FOLD=0/1 forces the choice (scripts/tune.py measures both)."""
+        w, v = self.pk.w, self.pk.v
+        mode = os.environ.get("UPGPT_LN_FOLD", "auto")
+        fold = mode != "0"
+        if mode == "auto":
+            pw = w[name]
+            args = (x.M, pw.n_pad, _rup(x.C, 32), 0, 1, 1, flags, False, False, "vt" in kw and kw["vt"] is not None)
+            e_ln = TUNE_CACHE.get(self.conv_key(*args, True))
+            e_pl = TUNE_CACHE.get(self.conv_key(*args, False))
+            if e_ln is not None and e_pl is not None:
+                fold = e_ln[2] < e_pl[2] + LN_LAUNCH_US
+        if fold:
+            return self.conv(P, x, w[name + "_ln"], flags=flags, ln_eps=1e-5, **kw)
+        return self.conv(P, self.layernorm(P, x, *v[norm]), w[name], flags=flags, **kw)
+
     def conv(self, P, x1, pw, *, x2=None, stride=1, flags=0, residual=None, rowvec=None, rv_bs=0, rv_ss=0,
-             step=None, out=None, vt=None, nchw_out=None, out_f32=None, spatial=None):
+             step=None, out=None, vt=None, nchw_out=None, out_f32=None, spatial=None, ln_eps=None):
         """Emits one upk_conv2d_nhwc_f16. Returns the output Act (fp16) unless nchw_out /
         out_f32 is given."""
         B, H, W = spatial if spatial is not None else (x1.B, x1.H, x1.W)
@@ -282,8 +326,13 @@ class Emitter:
             d.vt_from, d.vt_heads, d.vt_dhead = vt["from"], vt["heads"], vt["dhead"]
             d.vt_ld, d.vt_tokens = vt["ld"], vt["tokens"]
         d.flags = flags
-        self.convs.append((d, "M%d_N%d_C%d+%d_k%ds%d_f%x_r%d%d%d" % (
-            M, pw.n_pad, d.c1, d.c2, ks, stride, flags, residual is not None, rowvec is not None, vt is not None)))
+        if ln_eps is not None:  # x1 is the un-normalised residual stream; pw was packed with ln=...
+            assert pw.ln_colsum is not None and x2 is None and ks == 1
+            d.ln_colsum = pw.ln_colsum.data_ptr()
+            d.ln_eps = float(ln_eps)
+            d.ln_dim = x1.C
+        self.convs.append((d, self.conv_key(M, pw.n_pad, d.c1, d.c2, ks, stride, flags, residual is not None,
+                                            rowvec is not None, vt is not None, ln_eps is not None)))
         fn, h, ref = self.lib.upk_conv2d_nhwc_f16, self.hctx, C.byref(d)
         chk = self._chk
         P.add(lambda s: chk(fn(h, ref, s)), d, pw, x1, x2, residual, rowvec, out, nchw_out, out_f32, vt,
@@ -356,15 +405,21 @@ class PackedUNet:
                 w[n + ".proj_in"] = pk.pack(n + ".proj_in")
                 t = n + ".transformer_blocks.0"
                 to_out_cols = pad_rows_map(1, heads, dh, dp)
-                w[t + ".attn1.qkv"] = pk.pack([t + ".attn1.to_q", t + ".attn1.to_k", t + ".attn1.to_v"],
-                                              row_map=pad_rows_map(3, heads, dh, dp), bias=False, n_out=2 * hd)
+                # norm1 / norm2 / norm3 can be folded into their only consumers (Emitter.ln_linear decides
+                # per shape): both packings are kept, "<name>_ln" has the LayerNorm affine folded in
+                for sfx, fold in (("", None), ("_ln", True)):
+                    w[t + ".attn1.qkv" + sfx] = pk.pack(
+                        [t + ".attn1.to_q", t + ".attn1.to_k", t + ".attn1.to_v"], row_map=pad_rows_map(3, heads, dh, dp),
+                        bias=False, n_out=2 * hd, ln=(t + ".norm1") if fold else None)
+                    w[t + ".attn2.q" + sfx] = pk.pack(t + ".attn2.to_q", row_map=pad_rows_map(1, heads, dh, dp),
+                                                      bias=False, ln=(t + ".norm2") if fold else None)
+                    w[t + ".ff.geglu" + sfx] = pk.pack(t + ".ff.net.0.proj", row_map=geglu_rows_map(4 * heads * dh),
+                                                       n_out=4 * heads * dh, ln=(t + ".norm3") if fold else None)
                 w[t + ".attn1.to_out"] = pk.pack(t + ".attn1.to_out.0", col_map=to_out_cols)
-                w[t + ".attn2.q"] = pk.pack(t + ".attn2.to_q", row_map=pad_rows_map(1, heads, dh, dp), bias=False)
                 w[t + ".attn2.kv"] = pk.pack([t + ".attn2.to_k", t + ".attn2.to_v"],
                                              row_map=pad_rows_map(2, heads, dh, dp), bias=False, n_out=hd)
                 w[t + ".attn2.to_out"] = pk.pack(t + ".attn2.to_out.0", col_map=to_out_cols)
                 inner = heads * dh
-                w[t + ".ff.geglu"] = pk.pack(t + ".ff.net.0.proj", row_map=geglu_rows_map(4 * inner), n_out=4 * inner)
                 w[t + ".ff.out"] = pk.pack(t + ".ff.net.2")
                 for k in ("norm1", "norm2", "norm3"):
                     norm(t + "." + k)
@@ -479,20 +534,18 @@ class UNetPlan(Emitter):
         xn = self.groupnorm(P, x, g, b, 1e-6, False, self.gn_ws)
         t0 = self.conv(P, xn, w[n + ".proj_in"])
         # self-attention
-        n1 = self.layernorm(P, t0, *v[t + ".norm1"])
         qk = Act(self.alloc(M, 2 * hd), B, x.H, x.W, 2 * hd)
         vt_ld = _rup(HW, 32)
         vt = self.alloc(B, heads, dp, vt_ld, zero=True)
-        self.conv(P, n1, w[t + ".attn1.qkv"], out=qk,
-                  vt=dict(t=vt, heads=heads, dhead=dp, ld=vt_ld, tokens=HW, **{"from": 2 * hd}))
+        self.ln_linear(P, t0, t + ".attn1.qkv", t + ".norm1", out=qk,  # norm1 -> q|k|v (attention.py:203,212)
+                       vt=dict(t=vt, heads=heads, dhead=dp, ld=vt_ld, tokens=HW, **{"from": 2 * hd}))
         a1 = Act(self.alloc(M, hd), B, x.H, x.W, hd)
         self.attention(P, qk.t, 2 * hd, HW * 2 * hd, qk.t[:, hd:], 2 * hd, HW * 2 * hd, vt, vt_ld, a1.t, hd, HW * hd,
                        B, heads, HW, HW, dp, scale)
         P.attn_flops += 4 * B * heads * HW * HW * dh
         t1 = self.conv(P, a1, w[t + ".attn1.to_out"], residual=t0)
         # cross-attention over the (precomputed) context K / V
-        n2 = self.layernorm(P, t1, *v[t + ".norm2"])
-        q2 = self.conv(P, n2, w[t + ".attn2.q"])
+        q2 = self.ln_linear(P, t1, t + ".attn2.q", t + ".norm2")
         kc, vtc, cld = self.kv[n]
         a2 = Act(self.alloc(M, hd), B, x.H, x.W, hd)
         self.attention(P, q2.t, hd, HW * hd, kc.t, hd, self.n_ctx * hd, vtc, cld, a2.t, hd, HW * hd, B, heads, HW,
@@ -500,8 +553,7 @@ class UNetPlan(Emitter):
         P.attn_flops += 4 * B * heads * HW * self.n_ctx * dh
         t2 = self.conv(P, a2, w[t + ".attn2.to_out"], residual=t1)
         # GEGLU feed-forward
-        n3 = self.layernorm(P, t2, *v[t + ".norm3"])
-        ff = self.conv(P, n3, w[t + ".ff.geglu"], flags=L.F_GEGLU)
+        ff = self.ln_linear(P, t2, t + ".ff.geglu", t + ".norm3", flags=L.F_GEGLU)
         t3 = self.conv(P, ff, w[t + ".ff.out"], residual=t2)
         return self.conv(P, t3, w[n + ".proj_out"], residual=x)
 
