@@ -13,6 +13,8 @@
 // V arrives transposed ([B, heads, d, vt_ld]) straight from the projection GEMM's epilogue
 // (igemm.hip, vt_* fields), K/Q are token-major with heads side by side.  K/V fragments are
 // read through L1/L2 (per (b, head) they are <= 200 KB and shared by all query tiles).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -195,6 +197,151 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Self-attention with long key sequences (UNet level 1: 1024 / 768 keys, d = 32): the direct
+// form above makes every wave pull its own K / V^T fragments through the CU's L1 — 16 cache
+// lines per load instruction, 32..64 useful bytes per line, the same data four times per
+// workgroup — and the level-1 launches sit at ~48 us for 8.6 GFLOP.  Here the workgroup stages each
+// 64-key tile ONCE in LDS (16-byte coalesced global loads, register double buffering, one barrier
+// per tile) and the four waves read their MFMA fragments from LDS:
+//   K tile  [kd][64 keys][32 halfs], 16-byte chunks XOR-swizzled like the igemm tiles;
+//   V^T tile [D rows][64 keys + 8 pad]  (144-byte rows: the 8-byte fragment reads spread over banks).
+constexpr int ATT_VROW = 72;
+__device__ __forceinline__ int att_swz(int row, int chunk) { return chunk ^ ((-(row >> 2)) & 3); }
+
+template <int D, int QT>
+__global__ __launch_bounds__(256) void attn_lds_kernel(const AttnArgs a) {
+  constexpr int KD = D / 32;
+  constexpr int DT = D / 16;
+  __shared__ __attribute__((aligned(16))) f16 sk[2][KD * 64 * 32];
+  __shared__ __attribute__((aligned(16))) f16 sv[2][D * ATT_VROW];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int bh = blockIdx.y;
+  const int b = bh / a.heads;
+  const int h = bh - b * a.heads;
+  const int q0 = (blockIdx.x * 4 + wave) * 16 * QT;
+  const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  bool q_ok[QT];
+  f16x8 qf[QT][KD];
+  f32x4 o[QT][DT];
+  float mrun[QT], lrun[QT];
+#pragma unroll
+  for (int u = 0; u < QT; ++u) {
+    const int qi = q0 + u * 16 + c;
+    q_ok[u] = qi < a.nq;
+    const f16* qrow = a.q + b * a.qbs + (long)(q_ok[u] ? qi : 0) * a.ldq + h * D + g * 8;
+#pragma unroll
+    for (int kd = 0; kd < KD; ++kd) qf[u][kd] = q_ok[u] ? *(const f16x8*)(qrow + kd * 32) : zero8;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[u][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mrun[u] = -INFINITY;
+    lrun[u] = 0.f;
+  }
+  // staging assignment: K element (kd = it, key = tid>>2, chunk = tid&3); V^T element (row = (tid + 256 it)>>3, col = tid&7)
+  const f16* ksrc = a.k + b * a.kbs + (long)(tid >> 2) * a.ldk + h * D + (tid & 3) * 8;
+  const f16* vsrc = a.vt + ((long)(b * a.heads + h) * D + (tid >> 3)) * a.vt_ld + (tid & 7) * 8;
+  const int kdst = (tid >> 2) * 32 + att_swz(tid >> 2, tid & 3) * 8;
+  const int vdst = (tid >> 3) * ATT_VROW + (tid & 7) * 8;
+  f16x8 kreg[KD], vreg[KD];
+  auto fetch = [&](int kb) {
+#pragma unroll
+    for (int it = 0; it < KD; ++it) {
+      kreg[it] = *(const f16x8*)(ksrc + (long)kb * a.ldk + it * 32);
+      vreg[it] = *(const f16x8*)(vsrc + (long)it * 32 * a.vt_ld + kb);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < KD; ++it) {
+      *(f16x8*)(&sk[buf][it * 64 * 32 + kdst]) = kreg[it];
+      *(f16x8*)(&sv[buf][it * 32 * ATT_VROW + vdst]) = vreg[it];
+    }
+  };
+  const int ntiles = a.nkv >> 6;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  const float cs = a.scale_log2;
+  const int kfrag = c * 32 + att_swz(c, g) * 8;
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) fetch((t + 1) << 6);
+    // ---- S^T = K Q^T for 64 keys ----
+    f32x4 sc[QT][4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int u = 0; u < QT; ++u) sc[u][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kd = 0; kd < KD; ++kd)
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const f16x8 kf = *(const f16x8*)(&sk[buf][(kd * 64 + tt * 16) * 32 + kfrag]);
+#pragma unroll
+        for (int u = 0; u < QT; ++u) sc[u][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[u][kd], sc[u][tt], 0, 0, 0);
+      }
+    // ---- online softmax (keys 16tt + 4g + r of query c) ----
+    f16x8 pf[QT][2];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+        mx = fmaxf(mx, fmaxf(fmaxf(sc[u][tt][0], sc[u][tt][1]), fmaxf(sc[u][tt][2], sc[u][tt][3])));
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float mnew = fmaxf(mrun[u], mx);
+      const float alpha = exp2f((mrun[u] - mnew) * cs);
+      mrun[u] = mnew;
+      const float mc = -mnew * cs;
+      float ps = 0.f;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = exp2f(fmaf(sc[u][tt][r], cs, mc));
+          ps += p;
+          pf[u][tt >> 1][(tt & 1) * 4 + r] = (f16)p;
+        }
+      lrun[u] = lrun[u] * alpha + ps;
+#pragma unroll
+      for (int i = 0; i < DT; ++i) o[u][i] *= alpha;
+    }
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const f16* vr = &sv[buf][(i * 16 + c) * ATT_VROW + 32 * j + 4 * g];
+        const f16x4 va = *(const f16x4*)vr, vb = *(const f16x4*)(vr + 16);
+        const f16x8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+#pragma unroll
+        for (int u = 0; u < QT; ++u) o[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[u][j], o[u][i], 0, 0, 0);
+      }
+    if (t + 1 < ntiles) stash(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < QT; ++u) {
+    float l = lrun[u];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    if (!q_ok[u]) continue;
+    f16* orow = a.o + b * a.obs + (long)(q0 + u * 16 + c) * a.ldo + h * D + g * 4;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) {
+      f16x4 ov;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ov[r] = (f16)(o[u][i][r] * inv);
+      *(f16x4*)(orow + i * 16) = ov;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int upk_attention_f16(upk_ctx* ctx, const void* q, int ldq, long long qbs, const void* k, int ldk,
@@ -227,6 +374,18 @@ extern "C" int upk_attention_f16(upk_ctx* ctx, const void* q, int ldq, long long
   const int qt = (d <= 128 && (long)((n_q + 127) / 128) * batch * heads >= 2L * ctx->num_cus) ? 2 : 1;
   dim3 grid((n_q + 64 * qt - 1) / (64 * qt), batch * heads), block(256);
   upk_prof_scope prof(ctx, UPK_CLS_ATTN, stream);
+  // long self-attention sequences: K / V^T tiles shared through LDS (whole 64-key tiles only)
+  static const bool lds_off = getenv("UPK_ATTN_DIRECT") != nullptr;
+  if (!lds_off && (d == 32 || d == 64) && n_kv >= 256 && (n_kv & 63) == 0 && (vt_ld & 7) == 0) {
+    if (d == 32) {
+      if (qt == 2) hipLaunchKernelGGL((attn_lds_kernel<32, 2>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((attn_lds_kernel<32, 1>), grid, block, 0, stream, a);
+    } else {
+      if (qt == 2) hipLaunchKernelGGL((attn_lds_kernel<64, 2>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((attn_lds_kernel<64, 1>), grid, block, 0, stream, a);
+    }
+    return upk_check_launch(ctx, "attention_lds");
+  }
 #define UPK_ATTN(D_, QR_)                                                                         \
   if (qt == 2)                                                                                    \
     hipLaunchKernelGGL((attn_kernel<D_, QR_, (D_ <= 128 ? 2 : 1)>), grid, block, 0, stream, a);  \
