@@ -130,6 +130,13 @@ typedef struct upk_conv_desc {
   const float* ln_colsum;
   float ln_eps;
   int32_t ln_dim;
+  /* GroupNorm statistics of the OUTPUT from the split-K reduce pass: when gn_stats_ws != NULL and the launch
+   * splits K (its second pass touches every output element anyway), that pass also writes the per-chunk
+   * (sum, sum of squares) partials of upk_groupnorm_nhwc_f16 for an [batch, Ho*Wo, n_out] tensor with gn_groups
+   * groups into gn_stats_ws (upk_groupnorm_ws_bytes(batch, Ho*Wo) bytes), so that the following GroupNorm can
+   * run upk_groupnorm_apply_nhwc_f16 only.  upk_conv_gn_fused() tells whether a descriptor will do so. */
+  float* gn_stats_ws;
+  int32_t gn_groups;
 } upk_conv_desc;
 
 /* Replaces F.conv2d (3x3 s1/s2 p1, 1x1) / F.linear call sites:
@@ -139,6 +146,11 @@ typedef struct upk_conv_desc {
  * time_embed/emb_layers (openaimodel.py:506-511,220), VAE Decoder convs
  * (model.py:462-568).  A Linear is ksize=1, batch=1, in_h=M, in_w=1. */
 int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream);
+
+/* *fused = 1 iff upk_conv2d_nhwc_f16(d) will write GroupNorm partials into d->gn_stats_ws (split-K launch with
+ * a plain fp16 NHWC epilogue, n_out % 8 == 0, 16-byte aligned rows), else 0.  Same decision procedure as the launch
+ * (tuned / overridden / cost-model split-K), nothing is enqueued. */
+int upk_conv_gn_fused(upk_ctx* ctx, const upk_conv_desc* d, int* fused);
 
 /* Convenience wrapper: y[M,N] = act(A[M,K] @ W^T + bias) + residual. */
 int upk_gemm_f16(upk_ctx* ctx, const void* a, int lda, int m, int k, const void* w_packed,
@@ -186,6 +198,12 @@ int upk_groupnorm_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int ld1, const 
                            const float* beta, float eps, int fuse_silu, void* y, int ldy,
                            float* stats_ws, upk_stream stream);
 size_t upk_groupnorm_ws_bytes(int batch, int hw);
+/* Second half of upk_groupnorm_nhwc_f16 only: stats_ws already holds the partial sums of this tensor
+ * (written by a split-K conv launch with gn_stats_ws set, see upk_conv_desc). */
+int upk_groupnorm_apply_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* x2, int c2,
+                                 int ld2, int batch, int hw, int groups, const float* gamma,
+                                 const float* beta, float eps, int fuse_silu, void* y, int ldy,
+                                 const float* stats_ws, upk_stream stream);
 
 /* LayerNorm over the last dim of fp16 [rows, d] (attention.py:203-205, eps 1e-5). */
 int upk_layernorm_f16(upk_ctx* ctx, const void* x, int ldx, int rows, int d, const float* gamma,

@@ -262,6 +262,50 @@ def test_gemm_with_folded_layernorm(ctx, M, d, N, geglu):
     ctx.conv_override(-1, 0)
 
 
+@pytest.mark.parametrize("cin,cout,hw,res", [(896, 896, (8, 8), True), (448, 448, (16, 12), False), (1792, 896, (4, 4), True)])
+def test_splitk_reduce_emits_groupnorm_partials(ctx, cin, cout, hw, res):
+    """A split-K conv's reduce pass writes the GroupNorm partial sums of its output (upk_conv_desc.gn_stats_ws):
+    GroupNorm apply-only on them must equal the two-pass GroupNorm bit for bit; without split-K nothing is
+    produced and upk_conv_gn_fused says so."""
+    B, (H, W) = 3, hw
+    x = rnd(B * H * W, cin).half()
+    w = rnd(cout, cin, 3, 3, scale=1 / math.sqrt(9 * cin))
+    b = rnd(cout, scale=0.1)
+    r = rnd(B * H * W, cout, seed=7).half() if res else None
+    wp, n_pad = ctx.pack_weight(w)
+    bp = torch.zeros(n_pad, device=DEV); bp[:cout] = b
+    y = torch.zeros(B * H * W, cout, device=DEV, dtype=torch.float16)
+    sws = torch.full((ctx.groupnorm_ws_bytes(B, H * W) // 4,), float("nan"), device=DEV)
+    d = L.ConvDesc()
+    d.x1 = x.data_ptr(); d.c1 = cin; d.ld1 = cin; d.batch = B; d.in_h = H; d.in_w = W; d.ksize = 3; d.stride = 1
+    d.w_packed = wp.data_ptr(); d.n_out = cout; d.n_pad = n_pad; d.bias = bp.data_ptr(); d.y = y.data_ptr(); d.ldy = cout
+    if res:
+        d.residual = r.data_ptr(); d.ld_res = cout
+    d.gn_stats_ws = sws.data_ptr(); d.gn_groups = 32
+    ref = F.conv2d(x.float().view(B, H, W, cin).permute(0, 3, 1, 2), w.half().float(), b, padding=1)
+    ref = ref.permute(0, 2, 3, 1).reshape(B * H * W, cout) + (r.float() if res else 0)
+    gamma, beta = 1 + 0.1 * rnd(cout, seed=2), 0.1 * rnd(cout, seed=3)
+    ws2 = torch.zeros(ctx.groupnorm_ws_bytes(B, H * W) // 4, device=DEV)
+    for sk in (4, 9):
+        ctx.conv_override(-1, sk)
+        assert ctx.conv_gn_fused(d)
+        y.zero_(); sws.fill_(float("nan"))
+        ctx.conv(d)
+        ctx.conv_override(-1, 0)
+        torch.cuda.synchronize()
+        check(y, ref)
+        full = torch.zeros_like(y); app = torch.zeros_like(y)
+        ctx.groupnorm(y, cout, cout, None, 0, 0, B, H * W, 32, gamma, beta, 1e-5, True, full, cout, ws2)
+        ctx._chk(ctx.lib.upk_groupnorm_apply_nhwc_f16(ctx.h, y.data_ptr(), cout, cout, None, 0, 0, B, H * W, 32,
+                                                      gamma.data_ptr(), beta.data_ptr(), 1e-5, 1, app.data_ptr(), cout,
+                                                      sws.data_ptr(), ctx._s()))
+        torch.cuda.synchronize()
+        assert torch.equal(full, app)
+    ctx.conv_override(-1, 1)
+    assert not ctx.conv_gn_fused(d)
+    ctx.conv_override(-1, 0)
+
+
 def test_qkv_gemm_with_transposed_v(ctx):
     """Fused q|k|v projection: q,k token-major, v written as V^T [B, heads, dpad, vt_ld];
     head dim 28 padded to 32 by the packing row map."""

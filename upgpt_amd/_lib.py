@@ -17,8 +17,9 @@ LIB_PATH = os.path.join(_HERE, "libupk.so")
 SYMBOLS = [
     "upk_version", "upk_create", "upk_destroy", "upk_last_error", "upk_set_workspace", "upk_num_cus",
     "upk_pack_weight_f16", "upk_packed_weight_bytes", "upk_conv2d_nhwc_f16", "upk_gemm_f16",
-    "upk_conv_autotune", "upk_conv_override", "upk_conv_num_configs", "upk_conv_config_name", "upk_attention_f16",
-    "upk_groupnorm_nhwc_f16", "upk_groupnorm_ws_bytes", "upk_layernorm_f16", "upk_timestep_embed_f16",
+    "upk_conv_autotune", "upk_conv_override", "upk_conv_num_configs", "upk_conv_config_name", "upk_conv_gn_fused",
+    "upk_attention_f16", "upk_groupnorm_nhwc_f16", "upk_groupnorm_apply_nhwc_f16", "upk_groupnorm_ws_bytes",
+    "upk_layernorm_f16", "upk_timestep_embed_f16",
     "upk_nchw_f32_to_nhwc_f16", "upk_nhwc_f16_to_nchw_f32", "upk_f32_to_f16", "upk_ddim_step_f32",
     "upk_advance_step", "upk_graph_begin", "upk_graph_end", "upk_graph_launch", "upk_graph_destroy",
     "upk_prof_enable", "upk_prof_collect",
@@ -52,6 +53,7 @@ class ConvDesc(C.Structure):
         ("vt_ld", C.c_int32), ("vt_tokens", C.c_int32), ("flags", C.c_int32),
         ("tune_cfg", C.c_int32), ("tune_splitk", C.c_int32),
         ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_dim", C.c_int32),
+        ("gn_stats_ws", C.c_void_p), ("gn_groups", C.c_int32),
     ]
 
 
@@ -92,6 +94,9 @@ def load_library(path=None):
                                             i32, i32, i32, i32, i32, f32, vp]),
             "upk_groupnorm_nhwc_f16": (C.c_int, [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp,
                                                  f32, i32, vp, i32, vp, vp]),
+            "upk_groupnorm_apply_nhwc_f16": (C.c_int, [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp,
+                                                       f32, i32, vp, i32, vp, vp]),
+            "upk_conv_gn_fused": (C.c_int, [vp, C.POINTER(ConvDesc), C.POINTER(C.c_int)]),
             "upk_groupnorm_ws_bytes": (C.c_size_t, [i32, i32]),
             "upk_layernorm_f16": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, f32, vp, i32, vp]),
             "upk_timestep_embed_f16": (C.c_int, [vp, vp, i32, i32, f32, vp, i32, vp]),
@@ -191,6 +196,11 @@ class Context:
         self._chk(self.lib.upk_groupnorm_nhwc_f16(self.h, _ptr(x1), c1, ld1, _ptr(x2), c2, ld2, batch, hw, groups,
                                                   _ptr(gamma), _ptr(beta), eps, int(silu), _ptr(y), ldy, _ptr(ws),
                                                   self._s()))
+
+    def conv_gn_fused(self, desc):
+        f = C.c_int(0)
+        self._chk(self.lib.upk_conv_gn_fused(self.h, C.byref(desc), C.byref(f)))
+        return bool(f.value)
 
     def groupnorm_ws_bytes(self, batch, hw):
         return self.lib.upk_groupnorm_ws_bytes(batch, hw)

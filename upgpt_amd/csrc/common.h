@@ -16,6 +16,18 @@ typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// GroupNorm partial-statistics chunking (norm.hip; the split-K reduce pass of igemm.hip writes the same layout):
+// ws[((b * nchunks + chunk) * groups + g) * 2 + {sum, sumsq}], chunk = pix_per_chunk consecutive pixels.
+constexpr int UPK_GN_MAX_CHUNKS = 32;
+constexpr int UPK_GN_GROUPS_MAX = 32;
+static inline void upk_gn_chunking(int hw, int* nchunks, int* pix_per_chunk) {
+  int n = hw < UPK_GN_MAX_CHUNKS ? hw : UPK_GN_MAX_CHUNKS;
+  if (n < 1) n = 1;
+  const int ppc = (hw + n - 1) / n;
+  *pix_per_chunk = ppc;
+  *nchunks = (hw + ppc - 1) / ppc;
+}
+
 enum { UPK_CLS_IGEMM = 0, UPK_CLS_ATTN = 1, UPK_CLS_GN = 2, UPK_CLS_LN = 3, UPK_CLS_OTHER = 4 };
 
 struct upk_prof_rec {

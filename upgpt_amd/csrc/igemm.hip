@@ -208,7 +208,7 @@ struct Epi {
   //   plain: fp32 acc + bias + timestep row vector + residual -> fp16 NHWC; absent operands point at
   //          the zero page instead of being branched around;
   //   geglu: (acc_v + b_v) * gelu(acc_g + b_g) -> fp16.
-  static __device__ __forceinline__ bool plain(const IgemmArgs& a) {
+  static __host__ __device__ __forceinline__ bool plain(const IgemmArgs& a) {
     return !(a.flags & (UPK_F_GEGLU | UPK_F_SILU | UPK_F_OUT_F32 | UPK_F_OUT_NCHW_F32)) && !a.vt && !(a.n_out & 3);
   }
   static __device__ __forceinline__ bool plain_geglu(const IgemmArgs& a) {
@@ -1011,6 +1011,100 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmArgs a, in
              Epi::fetch(b, rc, n));
 }
 
+// Split-K second pass that also takes the GroupNorm statistics of what it writes: grid (chunks, B) and
+// thread layout of gn_stats_kernel (norm.hip) — a thread owns 8 consecutive channels, `rpi` pixels in
+// flight — so the partial sums come out in upk_groupnorm's workspace layout and the GroupNorm that
+// follows a split-K conv (ResBlock out_layers / the next block's in_layers) needs its apply pass only.
+// Plain epilogue only (bias + timestep row vector + residual -> fp16 NHWC); statistics are taken from
+// the fp16-rounded values, exactly what gn_stats_kernel would read back.
+struct GnFuse {
+  float* ws;
+  int groups, cpg, hw, nchunks, pix_per_chunk;
+};
+
+__global__ __launch_bounds__(256) void igemm_reduce_gn_kernel(const IgemmArgs a, int splitk, const GnFuse gf) {
+  __shared__ float sc[2][256 * 8];
+  const int C = a.n_out;
+  const int vpr = C >> 3;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int p0 = chunk * gf.pix_per_chunk;
+  const int p1 = min(gf.hw, p0 + gf.pix_per_chunk);
+  const int rpi = 256 / vpr;
+  const int r = tid / vpr;
+  const int v = tid - r * vpr;
+  if (r < rpi) {
+    const int n = v * 8;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 c0 = z4, c1 = z4;  // per-column constants: bias + this sample's timestep row vector
+    if (a.bias) {
+      c0 = *(const f32x4*)(a.bias + n);
+      c1 = *(const f32x4*)(a.bias + n + 4);
+    }
+    if (a.rowvec) {
+      const int st = a.step ? *a.step : 0;
+      const float* rv = a.rowvec + (unsigned)(st * a.rv_ss + b * a.rv_bs) + n;
+      c0 += *(const f32x4*)rv;
+      c1 += *(const f32x4*)(rv + 4);
+    }
+    float s[8], ss[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
+    const long slab = (long)a.M * a.npad;
+    for (int p = p0 + r; p < p1; p += rpi) {
+      const long m = (long)b * gf.hw + p;
+      const float* pp = a.partial + m * a.npad + n;
+      f32x4 v0 = c0, v1 = c1;
+#pragma unroll 4
+      for (int z = 0; z < splitk; ++z) {
+        v0 += *(const f32x4*)(pp + z * slab);
+        v1 += *(const f32x4*)(pp + z * slab + 4);
+      }
+      if (a.res) {
+        const f16x8 rr = *(const f16x8*)(a.res + m * a.ldr + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v0[j] += (float)rr[j];
+          v1[j] += (float)rr[4 + j];
+        }
+      }
+      f16x8 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = (f16)v0[j];
+        o[4 + j] = (f16)v1[j];
+      }
+      *(f16x8*)((f16*)a.y + m * a.ldy + n) = o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = (float)o[j];
+        s[j] += f;
+        ss[j] += f * f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sc[0][r * C + v * 8 + j] = s[j];
+      sc[1][r * C + v * 8 + j] = ss[j];
+    }
+  }
+  __syncthreads();
+  // fold (row slot, channel) -> groups in the fixed order of gn_stats_kernel
+  const int q = tid >> 2, sub = tid & 3;
+  float t = 0.f;
+  if (q < gf.groups * 2) {
+    const int g = q >> 1, which = q & 1;
+    const int nel = rpi * gf.cpg;
+    for (int e = sub; e < nel; e += 4) {
+      const int rr = e / gf.cpg;
+      t += sc[which][rr * C + g * gf.cpg + (e - rr * gf.cpg)];
+    }
+  }
+  const float t1 = t + __shfl_xor(t, 1);
+  const float t2 = t1 + __shfl_xor(t1, 2);
+  if (q < gf.groups * 2 && sub == 0) gf.ws[((long)(b * gf.nchunks + chunk) * gf.groups) * 2 + q] = t2;
+}
+
 struct CfgInfo {
   int mi, ni, wm, wn, ks;
   const char* name;
@@ -1104,7 +1198,9 @@ extern "C" int upk_conv_override(upk_ctx* ctx, int cfg, int splitk) {
   return UPK_OK;
 }
 
-extern "C" int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_) {
+// launch == false: stops after the (config, split-K) decision and reports whether the reduce pass will
+// produce GroupNorm partials (upk_conv_gn_fused)
+static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, bool launch, int* gn_fused) {
   if (!ctx || !d) return UPK_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   if (!d->x1 || !d->w_packed || !d->y) return upk_fail(ctx, UPK_EINVAL, "conv: null x1/w/y");
@@ -1219,6 +1315,12 @@ extern "C" int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_str
   a.chunks_per_split = cdiv(a.nchunks, best_sk);
   const int zdim = cdiv(a.nchunks, a.chunks_per_split);
   a.partial = (zdim > 1) ? (float*)ctx->ws : nullptr;
+  // GroupNorm partials from the reduce pass (see igemm_reduce_gn_kernel)
+  const bool gn_fuse = d->gn_stats_ws && zdim > 1 && Epi::plain(a) && !(a.n_out & 7) && a.n_out <= 2048 &&
+                       d->gn_groups > 0 && d->gn_groups <= UPK_GN_GROUPS_MAX && a.n_out % d->gn_groups == 0 &&
+                       !(a.ldy & 7) && (!a.res || !(a.ldr & 7));
+  if (gn_fused) *gn_fused = gn_fuse ? 1 : 0;
+  if (!launch) return UPK_OK;
 
 #ifdef UPK_TIMELINE
   {  // dev: UPK_TL_TARGET=n stamps only the n-th conv launch of the process (e.g. one launch inside the forward graph)
@@ -1240,12 +1342,31 @@ extern "C" int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_str
   hipLaunchKernelGGL(c.fn, grid, dim3(c.nbuf ? 512 : c.wm * c.wn * 64), 0, stream, a);
   int rc = upk_check_launch(ctx, "igemm");
   if (rc) return rc;
-  if (zdim > 1) {
+  if (zdim > 1 && gn_fuse) {
+    GnFuse gf;
+    gf.ws = d->gn_stats_ws;
+    gf.groups = d->gn_groups;
+    gf.cpg = a.n_out / d->gn_groups;
+    gf.hw = a.Ho * a.Wo;
+    upk_gn_chunking(gf.hw, &gf.nchunks, &gf.pix_per_chunk);
+    hipLaunchKernelGGL(igemm_reduce_gn_kernel, dim3(gf.nchunks, a.B), dim3(256), 0, stream, a, zdim, gf);
+    rc = upk_check_launch(ctx, "igemm_reduce_gn");
+  } else if (zdim > 1) {
     const long total = (long)a.M * (a.npad / 4);
     hipLaunchKernelGGL(igemm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, zdim);
     rc = upk_check_launch(ctx, "igemm_reduce");
   }
   return rc;
+}
+
+extern "C" int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream) {
+  return conv_impl(ctx, d, stream, true, nullptr);
+}
+
+extern "C" int upk_conv_gn_fused(upk_ctx* ctx, const upk_conv_desc* d, int* fused) {
+  if (!fused) return UPK_EINVAL;
+  *fused = 0;
+  return conv_impl(ctx, d, nullptr, false, fused);
 }
 
 extern "C" int upk_conv_autotune(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, int reps, int* best_cfg,

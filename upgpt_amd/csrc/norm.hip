@@ -20,8 +20,8 @@
 
 namespace {
 
-constexpr int GN_MAX_CHUNKS = 32;
-constexpr int GN_GROUPS_MAX = 32;
+constexpr int GN_MAX_CHUNKS = UPK_GN_MAX_CHUNKS;
+constexpr int GN_GROUPS_MAX = UPK_GN_GROUPS_MAX;
 constexpr int GN_PREF = 4;  // x vectors prefetched per thread in gn_apply
 
 struct GnArgs {
@@ -258,24 +258,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* x, int ldx, i
   }
 }
 
-inline int gn_chunks(int hw) {
-  // as many chunks (= workgroups per sample) as the partial buffer allows: the deep UNet levels
-  // have only 16..64 pixels per sample and would otherwise run on a handful of CUs
-  int n = hw < GN_MAX_CHUNKS ? hw : GN_MAX_CHUNKS;
-  if (n < 1) n = 1;
-  return n;
-}
-
 }  // namespace
 
 extern "C" size_t upk_groupnorm_ws_bytes(int batch, int hw) {
-  return (size_t)batch * gn_chunks(hw) * GN_GROUPS_MAX * 2 * sizeof(float);
+  int nch, ppc;
+  upk_gn_chunking(hw, &nch, &ppc);
+  return (size_t)batch * nch * GN_GROUPS_MAX * 2 * sizeof(float);
 }
 
-extern "C" int upk_groupnorm_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* x2, int c2, int ld2,
-                                      int batch, int hw, int groups, const float* gamma, const float* beta,
-                                      float eps, int fuse_silu, void* y, int ldy, float* stats_ws,
-                                      upk_stream stream_) {
+static int gn_launch(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* x2, int c2, int ld2, int batch, int hw,
+                     int groups, const float* gamma, const float* beta, float eps, int fuse_silu, void* y, int ldy,
+                     float* stats_ws, upk_stream stream_, bool with_stats) {
   if (!ctx) return UPK_EINVAL;
   if (!x1 || !gamma || !beta || !y || !stats_ws) return upk_fail(ctx, UPK_EINVAL, "groupnorm: null pointer");
   const int C = c1 + c2;
@@ -295,9 +288,7 @@ extern "C" int upk_groupnorm_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int 
   a.hw = hw;
   a.groups = groups;
   a.cpg = C / groups;
-  a.nchunks = gn_chunks(hw);
-  a.pix_per_chunk = (hw + a.nchunks - 1) / a.nchunks;
-  a.nchunks = (hw + a.pix_per_chunk - 1) / a.pix_per_chunk;
+  upk_gn_chunking(hw, &a.nchunks, &a.pix_per_chunk);
   a.gamma = gamma;
   a.beta = beta;
   a.eps = eps;
@@ -306,9 +297,12 @@ extern "C" int upk_groupnorm_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int 
   a.ldy = ldy;
   a.ws = stats_ws;
   upk_prof_scope prof(ctx, UPK_CLS_GN, stream);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nchunks, batch), dim3(256), 0, stream, a);
-  int rc = upk_check_launch(ctx, "gn_stats");
-  if (rc) return rc;
+  int rc = UPK_OK;
+  if (with_stats) {
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nchunks, batch), dim3(256), 0, stream, a);
+    rc = upk_check_launch(ctx, "gn_stats");
+    if (rc) return rc;
+  }
   // apply: ~4 KB of fp16 per block (>= 3 blocks per CU on the UNet shapes: the kernel is a chain of
   // dependent memory round trips, so it needs co-resident blocks, not long per-block loops)
   int rows = (2048 + C - 1) / C;
@@ -316,6 +310,22 @@ extern "C" int upk_groupnorm_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int 
   const int blocks = (hw + rows - 1) / rows;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, batch), dim3(256), (size_t)C * 2 * sizeof(float), stream, a, rows);
   return upk_check_launch(ctx, "gn_apply");
+}
+
+extern "C" int upk_groupnorm_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* x2, int c2, int ld2,
+                                      int batch, int hw, int groups, const float* gamma, const float* beta,
+                                      float eps, int fuse_silu, void* y, int ldy, float* stats_ws,
+                                      upk_stream stream) {
+  return gn_launch(ctx, x1, c1, ld1, x2, c2, ld2, batch, hw, groups, gamma, beta, eps, fuse_silu, y, ldy, stats_ws,
+                   stream, true);
+}
+
+extern "C" int upk_groupnorm_apply_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* x2, int c2,
+                                            int ld2, int batch, int hw, int groups, const float* gamma,
+                                            const float* beta, float eps, int fuse_silu, void* y, int ldy,
+                                            const float* stats_ws, upk_stream stream) {
+  return gn_launch(ctx, x1, c1, ld1, x2, c2, ld2, batch, hw, groups, gamma, beta, eps, fuse_silu, y, ldy,
+                   (float*)stats_ws, stream, false);
 }
 
 extern "C" int upk_layernorm_f16(upk_ctx* ctx, const void* x, int ldx, int rows, int d, const float* gamma,

@@ -75,10 +75,11 @@ def head_pad(d):
 
 class Act:
     """[B*H*W, ld] fp16 activation (C valid channels)."""
-    __slots__ = ("t", "B", "H", "W", "C")
+    __slots__ = ("t", "B", "H", "W", "C", "gn_src")
 
     def __init__(self, t, B, H, W, C):
         self.t, self.B, self.H, self.W, self.C = t, B, H, W, C
+        self.gn_src = None  # (producer ConvDesc, stats buffer) when the producer may have left GroupNorm partials
 
     @property
     def ld(self):
@@ -268,7 +269,8 @@ class Emitter:
         return self.conv(P, self.layernorm(P, x, *v[norm]), w[name], flags=flags, **kw)
 
     def conv(self, P, x1, pw, *, x2=None, stride=1, flags=0, residual=None, rowvec=None, rv_bs=0, rv_ss=0,
-             step=None, out=None, vt=None, nchw_out=None, out_f32=None, spatial=None, ln_eps=None):
+             step=None, out=None, vt=None, nchw_out=None, out_f32=None, spatial=None, ln_eps=None,
+             gn_stats=False):
         """Emits one upk_conv2d_nhwc_f16. Returns the output Act (fp16) unless nchw_out /
         out_f32 is given."""
         B, H, W = spatial if spatial is not None else (x1.B, x1.H, x1.W)
@@ -326,6 +328,12 @@ class Emitter:
             d.vt_from, d.vt_heads, d.vt_dhead = vt["from"], vt["heads"], vt["dhead"]
             d.vt_ld, d.vt_tokens = vt["ld"], vt["tokens"]
         d.flags = flags
+        if gn_stats and ret is not None and vt is None and pw.n_out % 8 == 0 and pw.n_out % 32 == 0:
+            # if this launch splits K, its reduce pass also writes the GroupNorm partials of the output
+            # (include/upk.h gn_stats_ws); the GroupNorm that reads `ret` then runs its apply pass only
+            sws = self.alloc(self.lib.upk_groupnorm_ws_bytes(B, Ho * Wo) // 4, dtype=torch.float32)
+            d.gn_stats_ws, d.gn_groups = sws.data_ptr(), 32
+            ret.gn_src = (d, sws)
         if ln_eps is not None:  # x1 is the un-normalised residual stream; pw was packed with ln=...
             assert pw.ln_colsum is not None and x2 is None and ks == 1
             d.ln_colsum = pw.ln_colsum.data_ptr()
@@ -346,8 +354,25 @@ class Emitter:
         fn, h, chk = self.lib.upk_groupnorm_nhwc_f16, self.hctx, self._chk
         a = (x1.t.data_ptr(), x1.C, x1.ld, x2.t.data_ptr() if x2 is not None else None, x2.C if x2 is not None else 0,
              x2.ld if x2 is not None else 0, x1.B, x1.H * x1.W, 32, gamma.data_ptr(), beta.data_ptr(), float(eps),
-             int(bool(silu)), y.t.data_ptr(), y.ld, ws.data_ptr())
-        P.add(lambda s: chk(fn(h, *a, s)), x1, x2, gamma, beta, y, ws, cls="groupnorm")
+             int(bool(silu)), y.t.data_ptr(), y.ld)
+        src = getattr(x1, "gn_src", None) if x2 is None else None
+        if src is None:
+            P.add(lambda s: chk(fn(h, *a, ws.data_ptr(), s)), x1, x2, gamma, beta, y, ws, cls="groupnorm")
+        else:
+            # the producer conv may have left the partial statistics of x1 in its own buffer (split-K launches
+            # only; decided by the tuned / cost-model split factor at the time the program runs or is captured)
+            d, sws = src
+            fused_fn, apply_fn, dref = self.lib.upk_conv_gn_fused, self.lib.upk_groupnorm_apply_nhwc_f16, C.byref(d)
+
+            def run(s):
+                fused = C.c_int(0)
+                chk(fused_fn(h, dref, C.byref(fused)))
+                if fused.value:
+                    chk(apply_fn(h, *a, sws.data_ptr(), s))
+                else:
+                    chk(fn(h, *a, ws.data_ptr(), s))
+
+            P.add(run, x1, gamma, beta, y, ws, sws, d, cls="groupnorm")
         P.n_launch += 1  # stats + apply
         return y
 
@@ -511,7 +536,7 @@ class UNetPlan(Emitter):
                                  skip.H, skip.W, x.H, x.W, n, 2 ** (len(self.arch.channel_mult) - 1)))
         g, b = v[n + ".in_layers.0"]
         hN = self.groupnorm(P, x, g, b, 1e-5, True, self.gn_ws, x2=skip)
-        hh = self.conv(P, hN, w[n + ".in_layers.2"], **self._rv(n))
+        hh = self.conv(P, hN, w[n + ".in_layers.2"], gn_stats=True, **self._rv(n))
         g, b = v[n + ".out_layers.0"]
         hN = self.groupnorm(P, hh, g, b, 1e-5, True, self.gn_ws)
         if Lr.cin != Lr.cout:
@@ -519,7 +544,7 @@ class UNetPlan(Emitter):
         else:
             assert skip is None
             sk = x
-        return self.conv(P, hN, w[n + ".out_layers.3"], residual=sk)
+        return self.conv(P, hN, w[n + ".out_layers.3"], residual=sk, gn_stats=True)
 
     def _st(self, P, Lr, x):
         w, v = self.pk.w, self.pk.v
