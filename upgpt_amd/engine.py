@@ -243,10 +243,10 @@ class Emitter:
             self.ctx._chk(rc)
 
     @staticmethod
-    def conv_key(M, n_pad, c1, c2, ks, stride, flags, has_res, has_rowvec, has_vt, ln):
+    def conv_key(M, n_pad, c1, c2, ks, stride, flags, has_res, has_rowvec, has_vt, ln, gs=False):
         """Shape signature of one conv/GEMM launch = key of the tuning cache."""
-        return "M%d_N%d_C%d+%d_k%ds%d_f%x_r%d%d%d%s" % (M, n_pad, c1, c2, ks, stride, flags, has_res, has_rowvec,
-                                                       has_vt, "_ln" if ln else "")
+        return "M%d_N%d_C%d+%d_k%ds%d_f%x_r%d%d%d%s%s" % (M, n_pad, c1, c2, ks, stride, flags, has_res, has_rowvec,
+                                                         has_vt, "_ln" if ln else "", "_gs" if gs else "")
 
     def ln_linear(self, P, x, name, norm, flags=0, **kw):
         """LayerNorm `norm` followed by the Linear `name`: either one launch with the norm folded into the
@@ -340,7 +340,8 @@ class Emitter:
             d.ln_eps = float(ln_eps)
             d.ln_dim = x1.C
         self.convs.append((d, self.conv_key(M, pw.n_pad, d.c1, d.c2, ks, stride, flags, residual is not None,
-                                            rowvec is not None, vt is not None, ln_eps is not None)))
+                                            rowvec is not None, vt is not None, ln_eps is not None,
+                                            bool(d.gn_stats_ws))))
         fn, h, ref = self.lib.upk_conv2d_nhwc_f16, self.hctx, C.byref(d)
         chk = self._chk
         P.add(lambda s: chk(fn(h, ref, s)), d, pw, x1, x2, residual, rowvec, out, nchw_out, out_f32, vt,
