@@ -130,11 +130,15 @@ typedef struct upk_conv_desc {
   const float* ln_colsum;
   float ln_eps;
   int32_t ln_dim;
-  /* GroupNorm statistics of the OUTPUT from the split-K reduce pass: when gn_stats_ws != NULL and the launch
-   * splits K (its second pass touches every output element anyway), that pass also writes the per-chunk
-   * (sum, sum of squares) partials of upk_groupnorm_nhwc_f16 for an [batch, Ho*Wo, n_out] tensor with gn_groups
-   * groups into gn_stats_ws (upk_groupnorm_ws_bytes(batch, Ho*Wo) bytes), so that the following GroupNorm can
-   * run upk_groupnorm_apply_nhwc_f16 only.  upk_conv_gn_fused() tells whether a descriptor will do so. */
+  /* GroupNorm statistics of the OUTPUT as a by-product of the launch, so that the following GroupNorm can run
+   * upk_groupnorm_apply_nhwc_f16 only.  With gn_stats_ws != NULL and a plain fp16 NHWC epilogue
+   *   mode 1: a split-K launch's reduce pass (it touches every output element anyway) writes the per-chunk
+   *           per-group partials of upk_groupnorm_nhwc_f16 (n_out % 8 == 0, 16-byte aligned rows);
+   *   mode 2: an unsplit launch whose M tiles lie inside one sample writes per-(M tile, channel) partials
+   *           [batch][nblk][2][n_pad] from its epilogue.
+   * gn_stats_ws must hold batch * 32 * 2 * max(n_pad, 32) floats.  upk_conv_gn_fused() returns the mode (0 = none:
+   * the consumer has to run the full GroupNorm) and nblk for a descriptor; both depend on the tuned / overridden /
+   * cost-model (tile, split-K) choice, the same decision procedure as the launch. */
   float* gn_stats_ws;
   int32_t gn_groups;
 } upk_conv_desc;
@@ -147,10 +151,9 @@ typedef struct upk_conv_desc {
  * (model.py:462-568).  A Linear is ksize=1, batch=1, in_h=M, in_w=1. */
 int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream);
 
-/* *fused = 1 iff upk_conv2d_nhwc_f16(d) will write GroupNorm partials into d->gn_stats_ws (split-K launch with
- * a plain fp16 NHWC epilogue, n_out % 8 == 0, 16-byte aligned rows), else 0.  Same decision procedure as the launch
- * (tuned / overridden / cost-model split-K), nothing is enqueued. */
-int upk_conv_gn_fused(upk_ctx* ctx, const upk_conv_desc* d, int* fused);
+/* Which GroupNorm by-product upk_conv2d_nhwc_f16(d) will leave in d->gn_stats_ws (see upk_conv_desc): *mode in
+ * {0, 1, 2}, *nblk = row blocks per sample for mode 2.  Nothing is enqueued. */
+int upk_conv_gn_fused(upk_ctx* ctx, const upk_conv_desc* d, int* mode, int* nblk);
 
 /* Convenience wrapper: y[M,N] = act(A[M,K] @ W^T + bias) + residual. */
 int upk_gemm_f16(upk_ctx* ctx, const void* a, int lda, int m, int k, const void* w_packed,
@@ -198,12 +201,14 @@ int upk_groupnorm_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int ld1, const 
                            const float* beta, float eps, int fuse_silu, void* y, int ldy,
                            float* stats_ws, upk_stream stream);
 size_t upk_groupnorm_ws_bytes(int batch, int hw);
-/* Second half of upk_groupnorm_nhwc_f16 only: stats_ws already holds the partial sums of this tensor
- * (written by a split-K conv launch with gn_stats_ws set, see upk_conv_desc). */
+/* Second half of upk_groupnorm_nhwc_f16 only: stats_ws already holds the partial sums of this tensor, left by
+ * the conv launch that produced it (upk_conv_desc.gn_stats_ws): stats_mode / stats_nblk as reported by
+ * upk_conv_gn_fused, stats_ld = that launch's n_pad (mode 2; single-source input only). */
 int upk_groupnorm_apply_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* x2, int c2,
                                  int ld2, int batch, int hw, int groups, const float* gamma,
                                  const float* beta, float eps, int fuse_silu, void* y, int ldy,
-                                 const float* stats_ws, upk_stream stream);
+                                 const float* stats_ws, int stats_mode, int stats_nblk, int stats_ld,
+                                 upk_stream stream);
 
 /* LayerNorm over the last dim of fp16 [rows, d] (attention.py:203-205, eps 1e-5). */
 int upk_layernorm_f16(upk_ctx* ctx, const void* x, int ldx, int rows, int d, const float* gamma,

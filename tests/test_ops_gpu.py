@@ -275,7 +275,7 @@ def test_splitk_reduce_emits_groupnorm_partials(ctx, cin, cout, hw, res):
     wp, n_pad = ctx.pack_weight(w)
     bp = torch.zeros(n_pad, device=DEV); bp[:cout] = b
     y = torch.zeros(B * H * W, cout, device=DEV, dtype=torch.float16)
-    sws = torch.full((ctx.groupnorm_ws_bytes(B, H * W) // 4,), float("nan"), device=DEV)
+    sws = torch.full((ctx.gn_stats_floats(B, n_pad),), float("nan"), device=DEV)
     d = L.ConvDesc()
     d.x1 = x.data_ptr(); d.c1 = cin; d.ld1 = cin; d.batch = B; d.in_h = H; d.in_w = W; d.ksize = 3; d.stride = 1
     d.w_packed = wp.data_ptr(); d.n_out = cout; d.n_pad = n_pad; d.bias = bp.data_ptr(); d.y = y.data_ptr(); d.ldy = cout
@@ -288,7 +288,7 @@ def test_splitk_reduce_emits_groupnorm_partials(ctx, cin, cout, hw, res):
     ws2 = torch.zeros(ctx.groupnorm_ws_bytes(B, H * W) // 4, device=DEV)
     for sk in (4, 9):
         ctx.conv_override(-1, sk)
-        assert ctx.conv_gn_fused(d)
+        assert ctx.conv_gn_fused(d)[0] == 1
         y.zero_(); sws.fill_(float("nan"))
         ctx.conv(d)
         ctx.conv_override(-1, 0)
@@ -298,12 +298,38 @@ def test_splitk_reduce_emits_groupnorm_partials(ctx, cin, cout, hw, res):
         ctx.groupnorm(y, cout, cout, None, 0, 0, B, H * W, 32, gamma, beta, 1e-5, True, full, cout, ws2)
         ctx._chk(ctx.lib.upk_groupnorm_apply_nhwc_f16(ctx.h, y.data_ptr(), cout, cout, None, 0, 0, B, H * W, 32,
                                                       gamma.data_ptr(), beta.data_ptr(), 1e-5, 1, app.data_ptr(), cout,
-                                                      sws.data_ptr(), ctx._s()))
+                                                      sws.data_ptr(), 1, 0, n_pad, ctx._s()))
         torch.cuda.synchronize()
         assert torch.equal(full, app)
-    ctx.conv_override(-1, 1)
-    assert not ctx.conv_gn_fused(d)
-    ctx.conv_override(-1, 0)
+    # without split-K: per-(M tile, channel) partials from the epilogue (mode 2) where the tile configuration allows
+    # it (M tiles inside one sample, not the K-split kernels), otherwise mode 0 and nothing is promised
+    gref = F.silu(F.group_norm(ref.view(B, H * W, cout).permute(0, 2, 1), 32, gamma, beta, 1e-5)).permute(0, 2, 1)
+    modes = set()
+    for cfg in range(ctx.lib.upk_conv_num_configs()):
+        ctx.conv_override(cfg, 1)
+        try:
+            mode, nblk = ctx.conv_gn_fused(d)
+            modes.add(mode)
+            assert mode in (0, 2)
+            if mode == 2:
+                y.zero_(); sws.fill_(float("nan"))
+                ctx.conv(d)
+                app = torch.zeros_like(y)
+                ctx._chk(ctx.lib.upk_groupnorm_apply_nhwc_f16(
+                    ctx.h, y.data_ptr(), cout, cout, None, 0, 0, B, H * W, 32, gamma.data_ptr(), beta.data_ptr(), 1e-5, 1,
+                    app.data_ptr(), cout, sws.data_ptr(), 2, nblk, n_pad, ctx._s()))
+                torch.cuda.synchronize()
+                check(y, ref)
+                full = torch.zeros_like(y)
+                ctx.groupnorm(y, cout, cout, None, 0, 0, B, H * W, 32, gamma, beta, 1e-5, True, full, cout, ws2)
+                torch.cuda.synchronize()
+                assert (app.float() - full.float()).abs().max().item() <= 2e-3 * full.float().abs().max().item()
+                check(app.view(B, H * W, cout), gref, tol=1e-2)
+        except L.UpkError:
+            pass
+        finally:
+            ctx.conv_override(-1, 0)
+    assert 2 in modes
 
 
 def test_qkv_gemm_with_transposed_v(ctx):

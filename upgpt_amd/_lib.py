@@ -95,8 +95,8 @@ def load_library(path=None):
             "upk_groupnorm_nhwc_f16": (C.c_int, [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp,
                                                  f32, i32, vp, i32, vp, vp]),
             "upk_groupnorm_apply_nhwc_f16": (C.c_int, [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp,
-                                                       f32, i32, vp, i32, vp, vp]),
-            "upk_conv_gn_fused": (C.c_int, [vp, C.POINTER(ConvDesc), C.POINTER(C.c_int)]),
+                                                       f32, i32, vp, i32, vp, i32, i32, i32, vp]),
+            "upk_conv_gn_fused": (C.c_int, [vp, C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
             "upk_groupnorm_ws_bytes": (C.c_size_t, [i32, i32]),
             "upk_layernorm_f16": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, f32, vp, i32, vp]),
             "upk_timestep_embed_f16": (C.c_int, [vp, vp, i32, i32, f32, vp, i32, vp]),
@@ -198,9 +198,14 @@ class Context:
                                                   self._s()))
 
     def conv_gn_fused(self, desc):
-        f = C.c_int(0)
-        self._chk(self.lib.upk_conv_gn_fused(self.h, C.byref(desc), C.byref(f)))
-        return bool(f.value)
+        """(mode, nblk) of the GroupNorm by-product the launch of `desc` will leave (include/upk.h)."""
+        f, n = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.upk_conv_gn_fused(self.h, C.byref(desc), C.byref(f), C.byref(n)))
+        return f.value, n.value
+
+    def gn_stats_floats(self, batch, n_pad):
+        """Size (floats) of a upk_conv_desc.gn_stats_ws buffer."""
+        return batch * 32 * 2 * max(n_pad, 32)
 
     def groupnorm_ws_bytes(self, batch, hw):
         return self.lib.upk_groupnorm_ws_bytes(batch, hw)

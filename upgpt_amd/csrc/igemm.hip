@@ -60,6 +60,8 @@ struct IgemmArgs {
   int linear;      // ks == 1 && stride == 1 && !ups: rows are addressed directly
   unsigned long long* dbg;  // ABL_TIMELINE stamps
   const float* ln_u;  // folded LayerNorm: column sums of the packed (gamma-scaled) weight, or nullptr
+  float* gn_cp;       // plain epilogue also writes per-(row block, channel) GroupNorm partials here, or nullptr
+  int gn_nblk, gn_hw;  // row blocks (= M tiles) per sample, pixels per sample
   float ln_eps;
   float ln_inv_dim;
   int cpt;         // 32-wide chunks per tap = (c1+c2)/32
@@ -254,14 +256,29 @@ struct Epi {
     __device__ __forceinline__ f16x4 res4(const IgemmArgs& a, const Row& r, int n) const {
       return *(const f16x4*)(resp + r.res_off + ((n < a.n_out ? (unsigned)n : 0u) & has_res));
     }
-    static __device__ __forceinline__ void put(const IgemmArgs& a, const Row& r, int n, f32x4 v, const f16x4 rr) {
+    static __device__ __forceinline__ f16x4 put(const IgemmArgs& a, const Row& r, int n, f32x4 v, const f16x4 rr) {
       f16x4 o;
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] = (f16)(v[k] + (float)rr[k]);
       if (r.ok && n < a.n_out) *(f16x4*)((f16*)a.y + r.y_off + n) = o;
+      return o;
     }
   };
 
+  // sum over the 16 lanes of a DPP row (= the 16 rows a fragment's lanes with equal lg hold): rotate-add, every
+  // lane ends with the total
+  static __device__ __forceinline__ float row_sum16(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+  }
+
+  // tile_plain_cp: the tile also leaves the GroupNorm partial sums of what it stores: per (M tile, channel)
+  // sum / sum of squares of the fp16-rounded outputs — in-lane over the MI row fragments, rotate-add over
+  // the 16 rows of a fragment, through `red` (LDS, >= WM*WN*NI*32 floats) over the WM waves of a column, one
+  // fixed order -> bitwise reproducible.  The host guarantees an M tile lies inside one sample (BM | H*W).
   template <int MI, int NI>
   static __device__ __forceinline__ void tile_plain(const IgemmArgs& a, int mw, int nw, int lc, int lg,
                                                     const f32x4 (&acc)[MI][NI]) {
@@ -281,6 +298,79 @@ struct Epi {
       }
 #pragma unroll
       for (int j = 0; j < NI; ++j) Plain::put(a, r, nw + j * 16 + lg * 4, acc[i][j] + bv[j] + rv[j], rr[j]);
+    }
+  }
+
+  // (separate from tile_plain: the extra accumulators and the workgroup barrier must not weigh on every launch)
+  template <int MI, int NI, int WM, int WN>
+  static __device__ __forceinline__ void tile_plain_cp(const IgemmArgs& a, int m0, int mw, int nw, int lc, int lg,
+                                                       const f32x4 (&acc)[MI][NI], int wm, int wn, float* red) {
+    const Plain P(a);
+    constexpr bool cp = true;
+    f32x4 bv[NI];
+    f32x4 cs[NI], cq[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      bv[j] = P.bias4(a, nw + j * 16 + lg * 4);
+      cs[j] = cq[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const Plain::Row r = P.row(a, mw + i * 16 + lc);
+      f32x4 rv[NI];
+      f16x4 rr[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        rv[j] = P.rv4(a, r, nw + j * 16 + lg * 4);
+        rr[j] = P.res4(a, r, nw + j * 16 + lg * 4);
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const f16x4 o = Plain::put(a, r, nw + j * 16 + lg * 4, acc[i][j] + bv[j] + rv[j], rr[j]);
+        if (cp) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float f = (float)o[k];
+            cs[j][k] += f;
+            cq[j][k] += f * f;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        cs[j][k] = row_sum16(cs[j][k]);
+        cq[j][k] = row_sum16(cq[j][k]);
+      }
+    // red[(wm * WN + wn)][j][which][lg * 4 + k]
+    float* mine = red + ((wm * WN + wn) * NI) * 32 + lg * 4;
+    if (lc == 0) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        *(f32x4*)(mine + j * 32) = cs[j];
+        *(f32x4*)(mine + j * 32 + 16) = cq[j];
+      }
+    }
+    __syncthreads();
+    if (wm == 0 && lc == 0) {
+      const int b = m0 / a.gn_hw;
+      const int blk = (m0 - b * a.gn_hw) / (MI * 16 * WM);
+      float* dst = a.gn_cp + (long)((b * a.gn_nblk + blk) * 2) * a.npad;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = nw + j * 16 + lg * 4;
+        if (n >= a.npad) continue;
+        f32x4 su = {0.f, 0.f, 0.f, 0.f}, sq = su;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          su += *(const f32x4*)(red + ((w * WN + wn) * NI + j) * 32 + lg * 4);
+          sq += *(const f32x4*)(red + ((w * WN + wn) * NI + j) * 32 + 16 + lg * 4);
+        }
+        *(f32x4*)(dst + n) = su;
+        *(f32x4*)(dst + a.npad + n) = sq;
+      }
     }
   }
 
@@ -317,11 +407,12 @@ struct Epi {
   }
 
   // Epilogue of a wave's MI x NI register tile at (mw, nw).
-  template <int MI, int NI>
-  static __device__ __forceinline__ void tile(const IgemmArgs& a, int mw, int nw, int lc, int lg,
-                                              const f32x4 (&acc)[MI][NI]) {
+  template <int MI, int NI, int WM, int WN>
+  static __device__ __forceinline__ void tile(const IgemmArgs& a, int m0, int mw, int nw, int lc, int lg,
+                                              const f32x4 (&acc)[MI][NI], int wm, int wn, float* red) {
     if (plain(a)) {
-      tile_plain<MI, NI>(a, mw, nw, lc, lg, acc);
+      if (a.gn_cp) tile_plain_cp<MI, NI, WM, WN>(a, m0, mw, nw, lc, lg, acc, wm, wn, red);
+      else tile_plain<MI, NI>(a, mw, nw, lc, lg, acc);
       return;
     }
     if constexpr (NI % 4 == 0) {
@@ -577,7 +668,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
     }
     return;
   }
-  Epi::tile<MI, NI>(a, mw, nw, lc, lg, acc);
+  Epi::tile<MI, NI, WM, WN>(a, m0, mw, nw, lc, lg, acc, wm, wn, (float*)smem);
 }
 
 
@@ -887,12 +978,45 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
         rvs[q] = P.rv4(a, rows[q], n);
         rrs[q] = P.res4(a, rows[q], n);
       }
+      // GroupNorm channel partials (a.gn_cp, see Epi::tile_plain_cp): per finished fragment the 16-row sums go to
+      // LDS behind the K-slice buffer, then the MI row fragments of each column fragment are combined
+      static_assert(NF * 4096 + NF * 128 <= NBUF * STAGE * 2, "partials must fit behind the reduction buffer");
+      float* cpred = red + NF * 1024;  // [NF][2][16]
 #pragma unroll
       for (int q = 0; q < FW; ++q) {
         const int f = wave + 4 * q;
         if (f >= NF) continue;
         const int j = f - (f / NI) * NI;
-        Epi::Plain::put(a, rows[q], n0 + j * 16 + lg * 4, frag_sum(f) + bvs[q] + rvs[q], rrs[q]);
+        const f16x4 o = Epi::Plain::put(a, rows[q], n0 + j * 16 + lg * 4, frag_sum(f) + bvs[q] + rvs[q], rrs[q]);
+        if (a.gn_cp) {
+          f32x4 su, sq;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float v = (float)o[k];
+            su[k] = Epi::row_sum16(v);
+            sq[k] = Epi::row_sum16(v * v);
+          }
+          if (lc == 0) {
+            *(f32x4*)(cpred + f * 32 + lg * 4) = su;
+            *(f32x4*)(cpred + f * 32 + 16 + lg * 4) = sq;
+          }
+        }
+      }
+      if (a.gn_cp) {  // (workgroup-uniform)
+        __syncthreads();
+        const int b = m0 / a.gn_hw;
+        const int blk = (m0 - b * a.gn_hw) / (MI * 16);
+        float* dst = a.gn_cp + (long)((b * a.gn_nblk + blk) * 2) * a.npad;
+        if (lane < 32) {
+          const int which = lane >> 4, col = lane & 15;
+          for (int j = wave; j < NI; j += 4) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) t += cpred[(i * NI + j) * 32 + which * 16 + col];
+            const int n = n0 + j * 16 + col;
+            if (n < a.npad) dst[which * a.npad + n] = t;
+          }
+        }
       }
       return;
     }
@@ -974,7 +1098,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
     }
     return;
   }
-  Epi::tile<MI, NI>(a, mw, nw, lc, lg, acc);
+  Epi::tile<MI, NI, WM, WN>(a, m0, mw, nw, lc, lg, acc, wm, wn, (float*)smem);
 #ifdef UPK_TIMELINE
   if (wave == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1200,7 +1324,8 @@ extern "C" int upk_conv_override(upk_ctx* ctx, int cfg, int splitk) {
 
 // launch == false: stops after the (config, split-K) decision and reports whether the reduce pass will
 // produce GroupNorm partials (upk_conv_gn_fused)
-static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, bool launch, int* gn_fused) {
+static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, bool launch, int* gn_fused,
+                     int* gn_nblk = nullptr) {
   if (!ctx || !d) return UPK_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   if (!d->x1 || !d->w_packed || !d->y) return upk_fail(ctx, UPK_EINVAL, "conv: null x1/w/y");
@@ -1319,7 +1444,19 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   const bool gn_fuse = d->gn_stats_ws && zdim > 1 && Epi::plain(a) && !(a.n_out & 7) && a.n_out <= 2048 &&
                        d->gn_groups > 0 && d->gn_groups <= UPK_GN_GROUPS_MAX && a.n_out % d->gn_groups == 0 &&
                        !(a.ldy & 7) && (!a.res || !(a.ldr & 7));
-  if (gn_fused) *gn_fused = gn_fuse ? 1 : 0;
+  // ... or, without split-K, per-(M tile, channel) partials from the plain epilogue (Epi::tile_plain_cp and the
+  // K-split kernels' epilogue): needs M tiles that lie inside one sample
+  const int hw_out = a.Ho * a.Wo;
+  const bool gn_cp = d->gn_stats_ws && zdim == 1 && Epi::plain(a) && d->gn_groups > 0 &&
+                     d->gn_groups <= UPK_GN_GROUPS_MAX && a.n_out % d->gn_groups == 0 && a.n_out <= 2048 &&
+                     hw_out % BM == 0 && hw_out / BM <= UPK_GN_MAX_CHUNKS;
+  if (gn_cp) {
+    a.gn_cp = d->gn_stats_ws;
+    a.gn_nblk = hw_out / BM;
+    a.gn_hw = hw_out;
+  }
+  if (gn_fused) *gn_fused = gn_fuse ? 1 : (gn_cp ? 2 : 0);
+  if (gn_nblk) *gn_nblk = gn_cp ? a.gn_nblk : 0;
   if (!launch) return UPK_OK;
 
 #ifdef UPK_TIMELINE
@@ -1363,10 +1500,11 @@ extern "C" int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_str
   return conv_impl(ctx, d, stream, true, nullptr);
 }
 
-extern "C" int upk_conv_gn_fused(upk_ctx* ctx, const upk_conv_desc* d, int* fused) {
-  if (!fused) return UPK_EINVAL;
-  *fused = 0;
-  return conv_impl(ctx, d, nullptr, false, fused);
+extern "C" int upk_conv_gn_fused(upk_ctx* ctx, const upk_conv_desc* d, int* mode, int* nblk) {
+  if (!mode || !nblk) return UPK_EINVAL;
+  *mode = 0;
+  *nblk = 0;
+  return conv_impl(ctx, d, nullptr, false, mode, nblk);
 }
 
 constexpr float kGnStatsLaunchUs = 5.0f;  // gn_stats_kernel inside the replayed forward (rocprof: 5.7 us average)
@@ -1431,7 +1569,7 @@ extern "C" int upk_conv_autotune(upk_ctx* ctx, const upk_conv_desc* d, upk_strea
         if (time_one(c, sk, &us) != UPK_OK) continue;  // infeasible candidate
         // a split launch whose reduce pass writes the GroupNorm partials saves the consumer's gn_stats launch
         int fused = 0;
-        if (dd.gn_stats_ws && conv_impl(ctx, &dd, nullptr, false, &fused) == UPK_OK && fused) us -= kGnStatsLaunchUs;
+        if (dd.gn_stats_ws && conv_impl(ctx, &dd, nullptr, false, &fused) == UPK_OK && fused) us -= kGnStatsLaunchUs;  // either mode
         if (us < best) {
           best = us;
           bc = c;

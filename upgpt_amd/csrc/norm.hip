@@ -37,6 +37,8 @@ struct GnArgs {
   f16* y;
   int ldy;
   float* ws;  // [B][nchunks][groups][2]
+  // apply pass fed by a conv epilogue's per-(row block, channel) partials: ws = [B][cp_nblk][2][cp_ld]
+  int cp_nblk, cp_ld;
 };
 
 __device__ __forceinline__ f16x8 gn_load(const GnArgs& a, long pix, int v) {
@@ -130,6 +132,38 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a, int rows_
     pg[k] = ch < C ? a.gamma[ch] : 0.f;
     pb[k] = ch < C ? a.beta[ch] : 0.f;
   }
+  if (a.cp_nblk > 0) {
+    // per-(row block, channel) partials left by the producer conv's epilogue: fold the blocks per channel
+    // (threads walk channels: coalesced), then the channels of each group, both in a fixed order
+    float* chs = tab;  // [2][C] channel sums; overwritten by the scale / shift tables afterwards
+    const float* w = a.ws + (long)b * a.cp_nblk * 2 * a.cp_ld;
+    for (int idx = tid; idx < 2 * C; idx += 256) {
+      const int which = idx >= C ? 1 : 0;
+      const int ch = idx - which * C;
+      const float* src = w + which * a.cp_ld + ch;
+      float acc = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < a.cp_nblk; ++k) acc += src[(long)k * 2 * a.cp_ld];
+      chs[idx] = acc;
+    }
+    __syncthreads();
+    __shared__ double gsum[GN_GROUPS_MAX * 2];
+    if (tid < a.groups * 2) {
+      const int g = tid >> 1, which = tid & 1;
+      double acc = 0.0;
+      for (int e = 0; e < a.cpg; ++e) acc += (double)chs[which * C + g * a.cpg + e];
+      gsum[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < a.groups) {
+      const double n = (double)a.hw * a.cpg;
+      const double mean = gsum[tid * 2] / n;
+      double var = gsum[tid * 2 + 1] / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      smean[tid] = (float)mean;
+      srstd[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
+    }
+  } else {
   // fixed-order (bitwise reproducible) reduction of the chunk partials, 4 threads per
   // (group, sum|sumsq) so that the <= 64 loads per quantity are issued in parallel.
   {
@@ -161,6 +195,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a, int rows_
       smean[tid] = (float)mean;
       srstd[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
     }
+  }
   }
   __syncthreads();
   float* scale = tab;
@@ -268,7 +303,7 @@ extern "C" size_t upk_groupnorm_ws_bytes(int batch, int hw) {
 
 static int gn_launch(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* x2, int c2, int ld2, int batch, int hw,
                      int groups, const float* gamma, const float* beta, float eps, int fuse_silu, void* y, int ldy,
-                     float* stats_ws, upk_stream stream_, bool with_stats) {
+                     float* stats_ws, upk_stream stream_, bool with_stats, int cp_nblk = 0, int cp_ld = 0) {
   if (!ctx) return UPK_EINVAL;
   if (!x1 || !gamma || !beta || !y || !stats_ws) return upk_fail(ctx, UPK_EINVAL, "groupnorm: null pointer");
   const int C = c1 + c2;
@@ -296,6 +331,11 @@ static int gn_launch(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* 
   a.y = (f16*)y;
   a.ldy = ldy;
   a.ws = stats_ws;
+  a.cp_nblk = cp_nblk;
+  a.cp_ld = cp_ld;
+  if (cp_nblk > 0 && (c2 != 0 || cp_ld < C || cp_nblk > GN_MAX_CHUNKS))
+    return upk_fail(ctx, UPK_EINVAL, "groupnorm apply: channel partials need a single source, stats_ld >= C, nblk <= %d",
+                    GN_MAX_CHUNKS);
   upk_prof_scope prof(ctx, UPK_CLS_GN, stream);
   int rc = UPK_OK;
   if (with_stats) {
@@ -323,9 +363,12 @@ extern "C" int upk_groupnorm_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int 
 extern "C" int upk_groupnorm_apply_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* x2, int c2,
                                             int ld2, int batch, int hw, int groups, const float* gamma,
                                             const float* beta, float eps, int fuse_silu, void* y, int ldy,
-                                            const float* stats_ws, upk_stream stream) {
+                                            const float* stats_ws, int stats_mode, int stats_nblk, int stats_ld,
+                                            upk_stream stream) {
+  if (stats_mode != 1 && stats_mode != 2) return upk_fail(ctx, UPK_EINVAL, "groupnorm apply: stats_mode %d", stats_mode);
+  if (stats_mode == 2 && stats_nblk <= 0) return upk_fail(ctx, UPK_EINVAL, "groupnorm apply: stats_nblk %d", stats_nblk);
   return gn_launch(ctx, x1, c1, ld1, x2, c2, ld2, batch, hw, groups, gamma, beta, eps, fuse_silu, y, ldy,
-                   (float*)stats_ws, stream, false);
+                   (float*)stats_ws, stream, false, stats_mode == 2 ? stats_nblk : 0, stats_ld);
 }
 
 extern "C" int upk_layernorm_f16(upk_ctx* ctx, const void* x, int ldx, int rows, int d, const float* gamma,
