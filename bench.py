@@ -182,6 +182,34 @@ def cpu_baseline(hw, ddim_steps, batch):
             "unet_fwd_s": t_fwd, "decode_b1_s": t_dec}
 
 
+def upscale_secondary(ddim_steps, dev, batch=4, hw=(64, 64)):
+    """BASELINE configs[4] as worded there: the upscale model (models/upgpt/upscale/config.yaml) at bs=4 on a 64x64
+    latent, 50-step DDIM; UNet sampling loop only (its kl-f4 first stage is outside the path)."""
+    import upgpt_amd
+    from upgpt_amd import arch, synth
+    from upgpt_amd.ddim import DDIMSampler
+    m = quiet(upgpt_amd.build_model, "upscale", overrides={"image_size": list(hw)})
+    synth.fill_module_(m)
+    m = m.cuda()
+    inp = synth.synth_inputs(batch, hw, 3, 86, 768, seed=0, concat_channels=3)
+    cond = {"c_crossattn": inp["c_crossattn"].cuda(), "c_concat": [inp["c_concat"].cuda()]}
+    x_T = inp["x_T"].cuda()
+    sampler = DDIMSampler(m)
+
+    def run():
+        z, _ = sampler.sample(ddim_steps, batch, (3,) + tuple(hw), cond, eta=0.0, x_T=x_T, verbose=False,
+                              log_every_t=10 ** 6)
+        return z
+
+    quiet(run)
+    dt, z = timed(lambda: quiet(run), 2, dev)
+    assert torch.isfinite(z).all()
+    gf = arch.UNetArch(**synth.UPSCALE_UNET).flops(batch, hw[0], hw[1], 86) / 1e9
+    fwd_ms = dt / 2 / ddim_steps * 1e3
+    return {"value": batch * 2 / dt, "unit": "images/s (UNet DDIM loop, no decode)", "ms_per_unet_step": fwd_ms,
+            "algorithmic_gflop_per_fwd": gf, "mfma_util": gf * 1e9 / (fwd_ms * 1e-3) / (PEAK_MFMA_F16_TFLOPS * 1e12)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,6 +220,8 @@ def main():
     ap.add_argument("--latent", default="32x32", help="HxW of the latent (32x32 = 256x256 px)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--upscale", action="store_true",
+                    help="also time BASELINE configs[4]: the upscale UNet, bs=4, 64x64 latent, 50-step DDIM (UNet loop only)")
     args = ap.parse_args()
 
     from upgpt_amd import dist as D
@@ -261,6 +291,8 @@ def main():
             result["config_true_256x192"] = {"value": args.batch * max(2, args.steps // 2) / dt2, "unit": "images/s",
                                              "unet_fwd_ms_graph": unet_forward_ms(model, wl2),
                                              "algorithmic_gflop_per_fwd": a.flops(args.batch, 32, 24, 87) / 1e9}
+        if args.upscale and world == 1:
+            result["config_upscale_bs4_64x64"] = upscale_secondary(args.ddim_steps, dev)
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(hw, args.ddim_steps, args.batch)
         print(json.dumps(result), flush=True)
