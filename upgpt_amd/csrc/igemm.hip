@@ -839,7 +839,12 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
     };
     // waits until at most `r - 1` whole stages are still in flight (r = stages outstanding)
     auto wait_oldest = [&](int r) {
-      if (D >= 3 && r >= 3) wait_vmcnt<2 * P>();
+      static_assert(D <= 7, "wait ladder");
+      if (D >= 7 && r >= 7) wait_vmcnt<6 * P>();
+      else if (D >= 6 && r == 6) wait_vmcnt<(D >= 6 ? 5 : 0) * P>();
+      else if (D >= 5 && r == 5) wait_vmcnt<(D >= 5 ? 4 : 0) * P>();
+      else if (D >= 4 && r == 4) wait_vmcnt<(D >= 4 ? 3 : 0) * P>();
+      else if (D >= 3 && r == 3) wait_vmcnt<(D >= 3 ? 2 : 0) * P>();
       else if (r == 2) wait_vmcnt<P>();
       else wait_vmcnt<0>();
     };
@@ -1266,6 +1271,10 @@ const CfgInfo kCfgs[] = {
     // K-split across the MFMA waves (WM = WN = 1): block tile == register tile
     CFGW(2, 7, 1, 1, 4, 3), CFGW(4, 7, 1, 1, 4, 3), CFGW(2, 4, 1, 1, 4, 3), CFGW(4, 4, 1, 1, 4, 3),
     CFGW(2, 2, 1, 1, 4, 3), CFGW(4, 2, 1, 1, 4, 3), CFGW(1, 7, 1, 1, 4, 3), CFGW(4, 8, 1, 1, 4, 3),
+    // deep rings (5-7 stages in flight): the 8x8 / 4x4 levels stream 14-29 MB of cold weights per launch with only
+    // 64-512 output rows; with 2 stages in flight each workgroup pays one HBM round trip per ~32 KB
+    CFGW(2, 4, 2, 2, 2, 6), CFGW(4, 4, 2, 2, 1, 6), CFGW(2, 2, 2, 2, 2, 8), CFGW(2, 7, 4, 1, 1, 6),
+    CFGW(1, 4, 4, 1, 2, 8), CFGW(4, 2, 2, 2, 2, 6),
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
