@@ -220,6 +220,8 @@ def main():
     ap.add_argument("--latent", default="32x32", help="HxW of the latent (32x32 = 256x256 px)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--cfg", type=float, default=0.0,
+                    help="also time the main workload with classifier-free guidance at this scale (UNet on 2*B rows)")
     ap.add_argument("--upscale", action="store_true",
                     help="also time BASELINE configs[4]: the upscale UNet, bs=4, 64x64 latent, 50-step DDIM (UNet loop only)")
     args = ap.parse_args()
@@ -291,6 +293,20 @@ def main():
             result["config_true_256x192"] = {"value": args.batch * max(2, args.steps // 2) / dt2, "unit": "images/s",
                                              "unet_fwd_ms_graph": unet_forward_ms(model, wl2),
                                              "algorithmic_gflop_per_fwd": a.flops(args.batch, 32, 24, 87) / 1e9}
+        if args.cfg and world == 1:
+            uc = {"c_crossattn": torch.zeros_like(wl.cond["c_crossattn"]), "c_concat": wl.cond["c_concat"]}
+
+            def run_cfg():
+                with model.ema_scope():
+                    z, _ = wl.sampler.sample(wl.S, wl.B, (4,) + tuple(wl.hw), wl.cond, eta=0.0, x_T=wl.x_T, verbose=False,
+                                             log_every_t=10 ** 6, unconditional_guidance_scale=args.cfg,
+                                             unconditional_conditioning=uc)
+                return model.decode_first_stage(z)
+
+            quiet(run_cfg)
+            dtc, _ = timed(lambda: quiet(run_cfg), 2, dev)
+            result["config_cfg"] = {"value": args.batch * 2 / dtc, "unit": "images/s", "guidance_scale": args.cfg,
+                                    "ms_per_step": dtc / 2 * 1e3, "unet_rows": 2 * args.batch}
         if args.upscale and world == 1:
             result["config_upscale_bs4_64x64"] = upscale_secondary(args.ddim_steps, dev)
         if not args.no_cpu_baseline and world == 1:

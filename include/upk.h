@@ -243,6 +243,12 @@ int upk_f32_to_f16(upk_ctx* ctx, const float* x, int rows, int cols, void* y, in
 int upk_ddim_step_f32(upk_ctx* ctx, float* x, const float* eps, const float* coefs,
                       const float* noise, const int32_t* step, float* pred_x0, void* xin,
                       int ld_xin, int batch, int c, int hw, upk_stream stream);
+/* The same update with classifier-free guidance folded in (ddim.py:173-178): the UNet ran on 2*batch rows,
+ * [unconditional ; conditional]; eps2 is [2*batch, C, HW], e = e_u + scale * (e_c - e_u); x / pred_x0 / noise are
+ * [batch, ...]; x_prev refreshes BOTH halves of xin (fp16 NHWC [2*batch, HW, ld_xin]). */
+int upk_ddim_step_cfg_f32(upk_ctx* ctx, float* x, const float* eps2, const float* coefs,
+                          const float* noise, const int32_t* step, float* pred_x0, void* xin,
+                          int ld_xin, int batch, int c, int hw, float scale, upk_stream stream);
 /* *step += 1 (end of a captured step graph). */
 int upk_advance_step(upk_ctx* ctx, int32_t* step, upk_stream stream);
 

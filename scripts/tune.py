@@ -38,13 +38,15 @@ def summarize(name, emitter):
 
 for kind in kinds:
     with contextlib.redirect_stdout(io.StringIO()):
-        model = upgpt_amd.build_model(kind)
+        model = upgpt_amd.build_model("bbox" if kind == "bbox_cfg" else kind)
     synth.fill_module_(model)
     model = model.cuda()
     unet = model.model.diffusion_model
     C = model.channels
     ntok = 86 if kind == "upscale" else 87
     shapes = [(8, 32, 32, 50), (8, 32, 24, 50)] if kind == "bbox" else [(4, 64, 64, 50)]
+    if kind == "bbox_cfg":  # classifier-free guidance runs the UNet on 2*B rows
+        shapes, kind = [(16, 32, 32, 50), (16, 32, 24, 50)], "bbox"
     for (B, H, W, S) in shapes:
         for fold in ("1", "0"):  # LayerNorm folded into its consumer GEMM / separate: both get measured
             os.environ["UPGPT_LN_FOLD"] = fold

@@ -157,6 +157,24 @@ def test_general_path_equals_fused_path():
     zg, _ = s.sample(4, 2, (4, 32, 24), cond, eta=0.0, x_T=inp["x_T"].cuda(), verbose=False,
                      unconditional_guidance_scale=3.0, unconditional_conditioning=uc)
     assert torch.isfinite(zg).all() and zg.shape == (2, 4, 32, 24)
+    # ... which runs on the captured-graph fast path (one UNet pass over [uncond ; cond], guidance folded into the
+    # update kernel); it must agree with the step-by-step general path, eta = 0 and eta = 1 with injected noise
+    x = inp["x_T"].cuda()
+    for i, step in enumerate(np.flip(s.ddim_timesteps)):
+        ts = torch.full((2,), int(step), device="cuda", dtype=torch.long)
+        x, _ = s.p_sample_ddim(x, cond, ts, index=3 - i, unconditional_guidance_scale=3.0, unconditional_conditioning=uc)
+    assert mse(x, zg.cpu()) < 1e-6
+    assert mse(zg, z_fast.cpu()) > 1e-4  # guidance does change the result
+    noise = synth.synth_inputs(2, (32, 24), 4, 87, 768, seed=5, steps=4)["noise"].cuda()
+    zn, _ = s.sample(4, 2, (4, 32, 24), cond, eta=1.0, x_T=inp["x_T"].cuda(), verbose=False, normals_sequence=noise,
+                     unconditional_guidance_scale=2.0, unconditional_conditioning=uc)
+    s.make_schedule(4, ddim_eta=1.0, verbose=False)
+    x = inp["x_T"].cuda()
+    for i, step in enumerate(np.flip(s.ddim_timesteps)):
+        ts = torch.full((2,), int(step), device="cuda", dtype=torch.long)
+        x, _ = s.p_sample_ddim(x, cond, ts, index=3 - i, unconditional_guidance_scale=2.0, unconditional_conditioning=uc,
+                               noise=noise[i])
+    assert mse(x, zn.cpu()) < 1e-6
 
 
 def test_full_size_properties_b8_50_steps():

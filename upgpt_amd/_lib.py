@@ -21,6 +21,7 @@ SYMBOLS = [
     "upk_attention_f16", "upk_groupnorm_nhwc_f16", "upk_groupnorm_apply_nhwc_f16", "upk_groupnorm_ws_bytes",
     "upk_layernorm_f16", "upk_timestep_embed_f16",
     "upk_nchw_f32_to_nhwc_f16", "upk_nhwc_f16_to_nchw_f32", "upk_f32_to_f16", "upk_ddim_step_f32",
+    "upk_ddim_step_cfg_f32",
     "upk_advance_step", "upk_graph_begin", "upk_graph_end", "upk_graph_launch", "upk_graph_destroy",
     "upk_prof_enable", "upk_prof_collect",
 ]
@@ -104,6 +105,7 @@ def load_library(path=None):
             "upk_nhwc_f16_to_nchw_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, vp, vp]),
             "upk_f32_to_f16": (C.c_int, [vp, vp, i32, i32, vp, i32, vp]),
             "upk_ddim_step_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+            "upk_ddim_step_cfg_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
             "upk_advance_step": (C.c_int, [vp, vp, vp]),
             "upk_graph_begin": (C.c_int, [vp, vp]),
             "upk_graph_end": (C.c_int, [vp, vp, C.POINTER(vp)]),
@@ -230,6 +232,10 @@ class Context:
     def ddim_step(self, x, eps, coefs, noise, step, pred_x0, xin, ld_xin, batch, c, hw):
         self._chk(self.lib.upk_ddim_step_f32(self.h, _ptr(x), _ptr(eps), _ptr(coefs), _ptr(noise), _ptr(step),
                                              _ptr(pred_x0), _ptr(xin), ld_xin, batch, c, hw, self._s()))
+
+    def ddim_step_cfg(self, x, eps2, coefs, noise, step, pred_x0, xin, ld_xin, batch, c, hw, scale):
+        self._chk(self.lib.upk_ddim_step_cfg_f32(self.h, _ptr(x), _ptr(eps2), _ptr(coefs), _ptr(noise), _ptr(step),
+                                                 _ptr(pred_x0), _ptr(xin), ld_xin, batch, c, hw, float(scale), self._s()))
 
     def advance_step(self, step):
         self._chk(self.lib.upk_advance_step(self.h, _ptr(step), self._s()))

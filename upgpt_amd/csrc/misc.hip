@@ -189,6 +189,33 @@ __global__ void ddim_step_kernel(float* x, const float* eps, const float* coefs,
   }
 }
 
+// Classifier-free guidance inside the update (ddim.py:173-178): the UNet ran on [uncond ; cond] (2*batch rows),
+// eps = e_u + scale * (e_c - e_u); the new latent refreshes BOTH halves of the UNet stem input.
+__global__ void ddim_step_cfg_kernel(float* x, const float* eps2, const float* coefs, const float* noise, const int* step,
+                                     float* pred_x0, f16* xin, int ld_xin, int c, int hw, long n, float scale) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const int st = step ? *step : 0;
+  const float* cf = coefs + 4 * st;
+  const float c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
+  const float eu = eps2[idx], ec = eps2[n + idx];
+  const float xv = x[idx], e = eu + scale * (ec - eu);
+  const float p0 = (xv - c0 * e) * c1;
+  float xp = c2 * p0 + c3 * e;
+  if (noise) xp += noise[(long)st * n + idx];
+  x[idx] = xp;
+  if (pred_x0) pred_x0[idx] = p0;
+  if (xin) {
+    const long p = idx % hw;
+    const long t = idx / hw;
+    const long ch = t % c;
+    const long b = t / c;
+    const f16 h = (f16)xp;
+    xin[(b * hw + p) * ld_xin + ch] = h;
+    xin[(n / c + b * hw + p) * ld_xin + ch] = h;  // row offset batch*hw: the conditional half
+  }
+}
+
 __global__ void advance_step_kernel(int* step) { *step += 1; }
 
 }  // namespace
@@ -247,6 +274,19 @@ extern "C" int upk_ddim_step_f32(upk_ctx* ctx, float* x, const float* eps, const
   hipLaunchKernelGGL(ddim_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x, eps,
                      coefs, noise, step, pred_x0, (f16*)xin, ld_xin, c, hw, n);
   return upk_check_launch(ctx, "ddim_step");
+}
+
+extern "C" int upk_ddim_step_cfg_f32(upk_ctx* ctx, float* x, const float* eps2, const float* coefs, const float* noise,
+                                     const int32_t* step, float* pred_x0, void* xin, int ld_xin, int batch, int c, int hw,
+                                     float scale, upk_stream stream_) {
+  if (!ctx) return UPK_EINVAL;
+  if (!x || !eps2 || !coefs || batch <= 0 || c <= 0 || hw <= 0) return upk_fail(ctx, UPK_EINVAL, "ddim_step_cfg: bad args");
+  if (xin && ld_xin < c) return upk_fail(ctx, UPK_EINVAL, "ddim_step_cfg: ld_xin < c");
+  const long n = (long)batch * c * hw;
+  upk_prof_scope prof(ctx, UPK_CLS_OTHER, (hipStream_t)stream_);
+  hipLaunchKernelGGL(ddim_step_cfg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x, eps2,
+                     coefs, noise, step, pred_x0, (f16*)xin, ld_xin, c, hw, n, scale);
+  return upk_check_launch(ctx, "ddim_step_cfg");
 }
 
 extern "C" int upk_advance_step(upk_ctx* ctx, int32_t* step, upk_stream stream_) {

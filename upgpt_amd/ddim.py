@@ -95,27 +95,32 @@ class DDIMSampler(object):
         if ddim_use_original_steps or quantize_denoised or mask is not None or noise_dropout > 0. \
                 or score_corrector is not None:
             return False
-        if uc is not None and ucg_scale != 1.:
+        if uc is not None and ucg_scale != 1. and type(uc) is not type(cond):
             return False
         return hasattr(self.model, "_split_cond") and cond is not None
 
     def _fast_sampling(self, cond, shape, x_T, timesteps, callback, img_callback, log_every_t, temperature,
-                       normals_sequence):
+                       normals_sequence, cfg_scale=1., uc=None):
         model = self.model
         unet = model.model.diffusion_model
         b, C, H, W = shape
+        cfg = uc is not None and cfg_scale != 1.
+        if cfg:  # one UNet pass over [unconditional ; conditional] (ddim.py:173-178), combined in the update kernel
+            cond = self._cat_cond(uc, cond)
         c_concat, c_cross = model._split_cond(cond)
         S = int(timesteps.shape[0])
-        plan = unet.plan(b, H, W, c_cross.shape[1], S, "sampler")
+        plan = unet.plan(2 * b if cfg else b, H, W, c_cross.shape[1], S, "sampler")
         dev = plan.dev
         with torch.cuda.device(dev):
-            st = getattr(plan, "_sampler_state", None)
+            attr = "_sampler_state_cfg" if cfg else "_sampler_state"
+            st = getattr(plan, attr, None)
             if st is None:
                 from .engine import SamplerState
-                st = plan._sampler_state = SamplerState(plan, C)
+                st = SamplerState(plan, C, cfg=cfg)
+                setattr(plan, attr, st)
             img = torch.randn(shape, device=dev) if x_T is None else x_T.to(dev, torch.float32)
             st.x.copy_(img)
-            plan.load_x_nchw(st.x, 0, 0)
+            plan.load_x_nchw(torch.cat([st.x, st.x]) if cfg else st.x, 0, 0)
             ncat = 0
             if c_concat is not None:
                 ncat = c_concat.shape[1]
@@ -144,7 +149,7 @@ class DDIMSampler(object):
             print(f"Running DDIM Sampling with {S} timesteps")
             for i in range(S):
                 index = S - i - 1
-                st.launch(with_noise)
+                st.launch(with_noise, cfg_scale)
                 if callback:
                     callback(i)
                 if img_callback:
@@ -172,7 +177,8 @@ class DDIMSampler(object):
                          unconditional_guidance_scale, unconditional_conditioning) \
                 and len(timesteps) == len(self.ddim_timesteps):
             return self._fast_sampling(cond, shape, x_T, timesteps, callback, img_callback, log_every_t,
-                                       temperature, normals_sequence)
+                                       temperature, normals_sequence, cfg_scale=unconditional_guidance_scale,
+                                       uc=unconditional_conditioning)
 
         # general path: one apply_model + one fused update kernel per step, driven from Python
         img = torch.randn(shape, device=device) if x_T is None else x_T.to(device)

@@ -834,10 +834,15 @@ class SamplerState:
     pred_x0, the per-step coefficient / noise tables and the captured step graph
     (UNet body -> upk_ddim_step_f32 -> upk_advance_step)."""
 
-    def __init__(self, plan: UNetPlan, channels):
+    def __init__(self, plan: UNetPlan, channels, cfg=False):
+        """cfg: classifier-free guidance — the plan runs 2*B rows ([unconditional ; conditional], ddim.py:173-178),
+        the latent state has B = plan.B // 2 samples and the update combines the two halves of eps."""
         assert plan.mode == "sampler"
         self.plan = plan
-        B, H, W, R = plan.B, plan.H, plan.W, plan.rows
+        self.cfg = bool(cfg)
+        assert not cfg or plan.B % 2 == 0
+        B, H, W, R = (plan.B // 2 if cfg else plan.B), plan.H, plan.W, plan.rows
+        self.B = B
         self.C = channels
         self.x = plan.alloc(B, channels, H, W, dtype=torch.float32)
         self.pred_x0 = plan.alloc(B, channels, H, W, dtype=torch.float32)
@@ -848,25 +853,32 @@ class SamplerState:
     def ensure_noise(self):
         if self.noise is None:
             p = self.plan
-            self.noise = p.alloc(p.rows, p.B * self.C * p.H * p.W, dtype=torch.float32)
+            self.noise = p.alloc(p.rows, self.B * self.C * p.H * p.W, dtype=torch.float32)
         return self.noise
 
-    def _emit_tail(self, stream, with_noise):
+    def _emit_tail(self, stream, with_noise, scale=1.0):
         p = self.plan
-        p.ctx._chk(p.lib.upk_ddim_step_f32(p.hctx, self.x.data_ptr(), p.eps.data_ptr(), self.coefs.data_ptr(),
-                                           self.noise.data_ptr() if with_noise else None, p.step.data_ptr(),
-                                           self.pred_x0.data_ptr(), p.xin.t.data_ptr(), p.xin.ld, p.B, self.C,
-                                           p.H * p.W, stream))
+        nz = self.noise.data_ptr() if with_noise else None
+        if self.cfg:
+            p.ctx._chk(p.lib.upk_ddim_step_cfg_f32(p.hctx, self.x.data_ptr(), p.eps.data_ptr(), self.coefs.data_ptr(), nz,
+                                                   p.step.data_ptr(), self.pred_x0.data_ptr(), p.xin.t.data_ptr(),
+                                                   p.xin.ld, self.B, self.C, p.H * p.W, float(scale), stream))
+        else:
+            p.ctx._chk(p.lib.upk_ddim_step_f32(p.hctx, self.x.data_ptr(), p.eps.data_ptr(), self.coefs.data_ptr(), nz,
+                                               p.step.data_ptr(), self.pred_x0.data_ptr(), p.xin.t.data_ptr(), p.xin.ld,
+                                               p.B, self.C, p.H * p.W, stream))
         p.ctx._chk(p.lib.upk_advance_step(p.hctx, p.step.data_ptr(), stream))
 
-    def step_eager(self, with_noise):
+    def step_eager(self, with_noise, scale=1.0):
         s = self.plan.ctx._s()
         self.plan.body.run(s)
-        self._emit_tail(s, with_noise)
+        self._emit_tail(s, with_noise, scale)
 
-    def graph(self, with_noise):
-        """One DDIM step captured as a HIP graph (static shapes, device-side step index)."""
-        g = self.graphs.get(with_noise)
+    def graph(self, with_noise, scale=1.0):
+        """One DDIM step captured as a HIP graph (static shapes, device-side step index; the guidance scale is
+        a kernel argument, so each scale value gets its own graph)."""
+        key = (with_noise, float(scale) if self.cfg else 1.0)
+        g = self.graphs.get(key)
         if g is None:
             p = self.plan
             if with_noise:
@@ -877,15 +889,17 @@ class SamplerState:
             p.ctx._chk(p.lib.upk_graph_begin(p.hctx, sp))
             try:
                 p.body.run(sp)
-                self._emit_tail(sp, with_noise)
+                self._emit_tail(sp, with_noise, scale)
             finally:
                 gh = C.c_void_p()
                 rc = p.lib.upk_graph_end(p.hctx, sp, C.byref(gh))
             p.ctx._chk(rc)
             torch.cuda.current_stream(p.dev).wait_stream(side)
-            g = self.graphs[with_noise] = gh
+            if len(self.graphs) >= 8:  # guidance scales seen so far: bound the number of instantiated graphs
+                p.ctx.graph_destroy(self.graphs.pop(next(iter(self.graphs))))
+            g = self.graphs[key] = gh
         return g
 
-    def launch(self, with_noise):
+    def launch(self, with_noise, scale=1.0):
         p = self.plan
-        p.ctx._chk(p.lib.upk_graph_launch(p.hctx, self.graph(with_noise), p.ctx._s()))
+        p.ctx._chk(p.lib.upk_graph_launch(p.hctx, self.graph(with_noise, scale), p.ctx._s()))
