@@ -249,6 +249,16 @@ int upk_ddim_step_f32(upk_ctx* ctx, float* x, const float* eps, const float* coe
 int upk_ddim_step_cfg_f32(upk_ctx* ctx, float* x, const float* eps2, const float* coefs,
                           const float* noise, const int32_t* step, float* pred_x0, void* xin,
                           int ld_xin, int batch, int c, int hw, float scale, upk_stream stream);
+/* One model evaluation of the PLMS sampler (ldm/models/diffusion/plms.py:177-236; eta = 0), *step = evaluation
+ * counter k (S + 1 evaluations for S steps: the first step evaluates twice, pseudo improved Euler):
+ *   k = 0: predictor x~ = ddim(x, e0, coef[0]) goes to xin only; k = 1: e' = (e0 + eps)/2, x <- ddim(x, e', coef[0]);
+ *   k >= 2: e' = Adams-Bashforth of order min(k-1, 3)+1 over eps and the history; x <- ddim(x, e', coef[k-1]).
+ * hist: fp32 [3, n] eps history ring (owned by the caller, no initialisation needed); coefs as for upk_ddim_step_f32
+ * (one row per DDIM index); cfg != 0: eps holds [uncond ; cond] (2*batch) and e = e_u + cfg_scale*(e_c - e_u),
+ * xin has 2*batch*hw rows. */
+int upk_plms_step_f32(upk_ctx* ctx, float* x, const float* eps, const float* coefs, const int32_t* step,
+                      float* hist, float* pred_x0, void* xin, int ld_xin, int batch, int c, int hw,
+                      float cfg_scale, int cfg, upk_stream stream);
 /* *step += 1 (end of a captured step graph). */
 int upk_advance_step(upk_ctx* ctx, int32_t* step, upk_stream stream);
 

@@ -287,6 +287,30 @@ def test_plms_sampler_vs_reference_golden(kind):
     assert e < 1e-3 and len(inter["x_inter"]) == int(g["n_inter"])
     with pytest.raises(ValueError):
         PLMSSampler(model).sample(S=10, batch_size=B, shape=(k["C"], 32, 24), conditioning=cond, eta=0.5)
+    # the call above ran on the captured-graph fast path (eps history + Adams-Bashforth in upk_plms_step_f32);
+    # temperature != 1 forces the step-by-step general path, which must agree (sigma = 0: temperature is inert),
+    # with and without classifier-free guidance, and the intermediates / callbacks must line up
+    sm = PLMSSampler(model)
+    calls = []
+    zg, ig = sm.sample(S=10, batch_size=B, shape=(k["C"], 32, 24), conditioning=cond, eta=0.0, x_T=inp["x_T"][:B].cuda(),
+                       verbose=False, log_every_t=2, temperature=0.999)
+    zf, iff = sm.sample(S=10, batch_size=B, shape=(k["C"], 32, 24), conditioning=cond, eta=0.0, x_T=inp["x_T"][:B].cuda(),
+                        verbose=False, log_every_t=2, callback=lambda i: calls.append(i))
+    # (not bitwise: the Adams-Bashforth sum is evaluated in a different order; fp16 activations amplify that a little)
+    assert mse(zf, zg.cpu()) < 1e-4 and calls == list(range(10)) and len(iff["x_inter"]) == len(ig["x_inter"])
+    for a, b_ in zip(iff["pred_x0"], ig["pred_x0"]):
+        assert mse(a, b_.cpu()) < 1e-4
+    uc = {"c_crossattn": torch.zeros_like(cond["c_crossattn"]), "c_concat": cond["c_concat"]}
+    kw = dict(S=5, batch_size=B, shape=(k["C"], 32, 24), conditioning=cond, eta=0.0, x_T=inp["x_T"][:B].cuda(),
+              verbose=False, unconditional_guidance_scale=2.5, unconditional_conditioning=uc)
+    zc_fast, _ = sm.sample(**kw)
+    zc_gen, _ = sm.sample(temperature=0.999, **kw)
+    assert mse(zc_fast, zc_gen.cpu()) < 1e-4 and mse(zc_fast, zf.cpu()) > 1e-3
+    z1f, _ = sm.sample(S=1, batch_size=B, shape=(k["C"], 32, 24), conditioning=cond, eta=0.0, x_T=inp["x_T"][:B].cuda(),
+                       verbose=False)
+    z1g, _ = sm.sample(S=1, batch_size=B, shape=(k["C"], 32, 24), conditioning=cond, eta=0.0, x_T=inp["x_T"][:B].cuda(),
+                       verbose=False, temperature=0.999)
+    assert mse(z1f, z1g.cpu()) < 1e-5
 
 
 def test_square_latent_32x32_vs_oracle():

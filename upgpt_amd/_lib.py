@@ -21,7 +21,7 @@ SYMBOLS = [
     "upk_attention_f16", "upk_groupnorm_nhwc_f16", "upk_groupnorm_apply_nhwc_f16", "upk_groupnorm_ws_bytes",
     "upk_layernorm_f16", "upk_timestep_embed_f16",
     "upk_nchw_f32_to_nhwc_f16", "upk_nhwc_f16_to_nchw_f32", "upk_f32_to_f16", "upk_ddim_step_f32",
-    "upk_ddim_step_cfg_f32",
+    "upk_ddim_step_cfg_f32", "upk_plms_step_f32",
     "upk_advance_step", "upk_graph_begin", "upk_graph_end", "upk_graph_launch", "upk_graph_destroy",
     "upk_prof_enable", "upk_prof_collect",
 ]
@@ -106,6 +106,7 @@ def load_library(path=None):
             "upk_f32_to_f16": (C.c_int, [vp, vp, i32, i32, vp, i32, vp]),
             "upk_ddim_step_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
             "upk_ddim_step_cfg_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
+            "upk_plms_step_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
             "upk_advance_step": (C.c_int, [vp, vp, vp]),
             "upk_graph_begin": (C.c_int, [vp, vp]),
             "upk_graph_end": (C.c_int, [vp, vp, C.POINTER(vp)]),

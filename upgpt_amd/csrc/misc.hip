@@ -216,6 +216,63 @@ __global__ void ddim_step_cfg_kernel(float* x, const float* eps2, const float* c
   }
 }
 
+// One model evaluation of the PLMS sampler (plms.py:177-236), k = *step counts EVALUATIONS (S + 1 for S steps):
+//   k = 0: e0 = eps; pseudo improved Euler predictor: xin <- ddim(x, e0, coef[0]); x itself stays; hist <- e0
+//   k = 1: eps was evaluated at (predictor, t_1): e' = (e0 + eps) / 2; x <- ddim(x, e', coef[0])
+//   k >= 2: DDIM index j = k - 1: e' = Adams-Bashforth over [eps, e_{j-1}, e_{j-2}, e_{j-3}] by available history
+//           (3/2,-1/2 | 23/12,-16/12,5/12 | 55/24,-59/24,37/24,-9/24); x <- ddim(x, e', coef[j]); hist <- eps
+// eps may be the two halves of a classifier-free-guidance pass (eps2 = [uncond ; cond], scale), cfg_rows = 2.
+__global__ void plms_step_kernel(float* x, const float* eps, const float* coefs, const int* step, float* hist,
+                                 float* pred_x0, f16* xin, int ld_xin, int c, int hw, long n, int cfg_rows, float scale) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const int k = step ? *step : 0;
+  const int j = k == 0 ? 0 : k - 1;
+  const float* cf = coefs + 4 * j;
+  const float c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
+  float e = eps[idx];
+  if (cfg_rows == 2) e = e + scale * (eps[n + idx] - e);
+  float ep;
+  bool commit = true;
+  if (k == 0) {
+    ep = e;
+    commit = false;
+    hist[idx] = e;  // slot 0
+  } else if (k == 1) {
+    ep = 0.5f * (hist[idx] + e);
+  } else {
+    const float h1 = hist[(long)((j - 1) % 3) * n + idx];
+    if (j == 1) {
+      ep = 1.5f * e - 0.5f * h1;
+    } else {
+      const float h2 = hist[(long)((j - 2) % 3) * n + idx];
+      if (j == 2) {
+        ep = (23.f * e - 16.f * h1 + 5.f * h2) * (1.f / 12.f);
+      } else {
+        const float h3 = hist[(long)((j - 3) % 3) * n + idx];
+        ep = (55.f * e - 59.f * h1 + 37.f * h2 - 9.f * h3) * (1.f / 24.f);
+      }
+    }
+    hist[(long)(j % 3) * n + idx] = e;
+  }
+  const float xv = x[idx];
+  const float p0 = (xv - c0 * ep) * c1;
+  const float xp = c2 * p0 + c3 * ep;
+  if (commit) {
+    x[idx] = xp;
+    if (pred_x0) pred_x0[idx] = p0;
+  }
+  if (xin) {
+    const long p = idx % hw;
+    const long t = idx / hw;
+    const long ch = t % c;
+    const long b = t / c;
+    const f16 h = (f16)xp;
+    xin[(b * hw + p) * ld_xin + ch] = h;
+    if (cfg_rows == 2) xin[(n / c + b * hw + p) * ld_xin + ch] = h;
+  }
+}
+
 __global__ void advance_step_kernel(int* step) { *step += 1; }
 
 }  // namespace
@@ -287,6 +344,20 @@ extern "C" int upk_ddim_step_cfg_f32(upk_ctx* ctx, float* x, const float* eps2, 
   hipLaunchKernelGGL(ddim_step_cfg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x, eps2,
                      coefs, noise, step, pred_x0, (f16*)xin, ld_xin, c, hw, n, scale);
   return upk_check_launch(ctx, "ddim_step_cfg");
+}
+
+extern "C" int upk_plms_step_f32(upk_ctx* ctx, float* x, const float* eps, const float* coefs, const int32_t* step,
+                                 float* hist, float* pred_x0, void* xin, int ld_xin, int batch, int c, int hw,
+                                 float cfg_scale, int cfg, upk_stream stream_) {
+  if (!ctx) return UPK_EINVAL;
+  if (!x || !eps || !coefs || !step || !hist || batch <= 0 || c <= 0 || hw <= 0)
+    return upk_fail(ctx, UPK_EINVAL, "plms_step: bad args");
+  if (xin && ld_xin < c) return upk_fail(ctx, UPK_EINVAL, "plms_step: ld_xin < c");
+  const long n = (long)batch * c * hw;
+  upk_prof_scope prof(ctx, UPK_CLS_OTHER, (hipStream_t)stream_);
+  hipLaunchKernelGGL(plms_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x, eps,
+                     coefs, step, hist, pred_x0, (f16*)xin, ld_xin, c, hw, n, cfg ? 2 : 1, cfg_scale);
+  return upk_check_launch(ctx, "plms_step");
 }
 
 extern "C" int upk_advance_step(upk_ctx* ctx, int32_t* step, upk_stream stream_) {

@@ -834,12 +834,14 @@ class SamplerState:
     pred_x0, the per-step coefficient / noise tables and the captured step graph
     (UNet body -> upk_ddim_step_f32 -> upk_advance_step)."""
 
-    def __init__(self, plan: UNetPlan, channels, cfg=False):
+    def __init__(self, plan: UNetPlan, channels, cfg=False, plms=False):
         """cfg: classifier-free guidance — the plan runs 2*B rows ([unconditional ; conditional], ddim.py:173-178),
-        the latent state has B = plan.B // 2 samples and the update combines the two halves of eps."""
+        the latent state has B = plan.B // 2 samples and the update combines the two halves of eps.
+        plms: the graph is one PLMS model evaluation (upk_plms_step_f32; plan rows = evaluations = steps + 1)."""
         assert plan.mode == "sampler"
         self.plan = plan
         self.cfg = bool(cfg)
+        self.plms = bool(plms)
         assert not cfg or plan.B % 2 == 0
         B, H, W, R = (plan.B // 2 if cfg else plan.B), plan.H, plan.W, plan.rows
         self.B = B
@@ -849,6 +851,7 @@ class SamplerState:
         self.coefs = plan.alloc(R, 4, dtype=torch.float32)
         self.noise = None
         self.graphs = {}
+        self.hist = plan.alloc(3, B * channels * H * W, dtype=torch.float32) if plms else None
 
     def ensure_noise(self):
         if self.noise is None:
@@ -859,7 +862,13 @@ class SamplerState:
     def _emit_tail(self, stream, with_noise, scale=1.0):
         p = self.plan
         nz = self.noise.data_ptr() if with_noise else None
-        if self.cfg:
+        if self.plms:
+            assert not with_noise, "PLMS runs with eta = 0"
+            p.ctx._chk(p.lib.upk_plms_step_f32(p.hctx, self.x.data_ptr(), p.eps.data_ptr(), self.coefs.data_ptr(),
+                                               p.step.data_ptr(), self.hist.data_ptr(), self.pred_x0.data_ptr(),
+                                               p.xin.t.data_ptr(), p.xin.ld, self.B, self.C, p.H * p.W, float(scale),
+                                               int(self.cfg), stream))
+        elif self.cfg:
             p.ctx._chk(p.lib.upk_ddim_step_cfg_f32(p.hctx, self.x.data_ptr(), p.eps.data_ptr(), self.coefs.data_ptr(), nz,
                                                    p.step.data_ptr(), self.pred_x0.data_ptr(), p.xin.t.data_ptr(),
                                                    p.xin.ld, self.B, self.C, p.H * p.W, float(scale), stream))

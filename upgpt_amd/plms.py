@@ -1,10 +1,11 @@
 """PLMSSampler — drop-in for ldm.models.diffusion.plms.PLMSSampler: pseudo
 linear multistep (Adams-Bashforth on eps) over the same schedule tables as DDIM (eta must be 0).
 
-Round-1 state: runs on the general path — one UNetModel.forward (HIP kernels, eager launches)
-per model evaluation, the eps combination as tensor arithmetic and the x_prev / pred_x0 update
-in upk_ddim_step_f32.  The captured-graph fast path of DDIMSampler (device-side step counter,
-hoisted timestep MLP) is not wired for the eps history yet.
+Fast path (same conditions as DDIMSampler's): ONE captured HIP graph = UNet body + upk_plms_step_f32 +
+upk_advance_step, replayed S + 1 times (the first step evaluates the model twice); the eps history ring,
+the Adams-Bashforth combination and classifier-free guidance live in the update kernel, the timestep
+embeddings of all evaluations are precomputed like DDIM's.  Anything else (masks, score correctors, noise
+dropout) runs on the general path: one UNetModel.forward per model evaluation driven from Python.
 """
 import numpy as np
 import torch
@@ -46,12 +47,17 @@ class PLMSSampler(DDIMSampler):
             raise NotImplementedError("PLMS with the original 1000 steps / quantized x0 is not on the UPGPT path")
         device = self.model.betas.device
         b = shape[0]
-        img = torch.randn(shape, device=device) if x_T is None else x_T.to(device)
         if timesteps is None:
             timesteps = self.ddim_timesteps
         else:
             subset_end = int(min(timesteps / self.ddim_timesteps.shape[0], 1) * self.ddim_timesteps.shape[0]) - 1
             timesteps = self.ddim_timesteps[:subset_end]
+        if self._fast_ok(cond, ddim_use_original_steps, quantize_denoised, mask, noise_dropout, score_corrector,
+                         unconditional_guidance_scale, unconditional_conditioning) \
+                and len(timesteps) == len(self.ddim_timesteps) and temperature == 1.:
+            return self._fast_plms(cond, shape, x_T, timesteps, callback, img_callback, log_every_t,
+                                   unconditional_guidance_scale, unconditional_conditioning)
+        img = torch.randn(shape, device=device) if x_T is None else x_T.to(device)
         intermediates = {"x_inter": [img], "pred_x0": [img]}
         time_range = np.flip(timesteps)
         total = timesteps.shape[0]
@@ -80,6 +86,59 @@ class PLMSSampler(DDIMSampler):
                 intermediates["x_inter"].append(img)
                 intermediates["pred_x0"].append(pred_x0)
         return img, intermediates
+
+    def _fast_plms(self, cond, shape, x_T, timesteps, callback, img_callback, log_every_t, cfg_scale, uc):
+        from .ddim import ddim_coefficient_table
+        from .engine import SamplerState
+        model = self.model
+        unet = model.model.diffusion_model
+        b, C, H, W = shape
+        cfg = uc is not None and cfg_scale != 1.
+        if cfg:
+            cond = self._cat_cond(uc, cond)
+        c_concat, c_cross = model._split_cond(cond)
+        S = int(timesteps.shape[0])
+        plan = unet.plan(2 * b if cfg else b, H, W, c_cross.shape[1], S + 1, "sampler")  # rows = model evaluations
+        dev = plan.dev
+        with torch.cuda.device(dev):
+            attr = "_plms_state_cfg" if cfg else "_plms_state"
+            st = getattr(plan, attr, None)
+            if st is None:
+                st = SamplerState(plan, C, cfg=cfg, plms=True)
+                setattr(plan, attr, st)
+            img = torch.randn(shape, device=dev) if x_T is None else x_T.to(dev, torch.float32)
+            st.x.copy_(img)
+            plan.load_x_nchw(torch.cat([st.x, st.x]) if cfg else st.x, 0, 0)
+            if c_concat is not None:
+                plan.load_x_nchw(c_concat, C, plan.cin_pad)
+            assert C + (0 if c_concat is None else c_concat.shape[1]) == unet.in_channels
+            order = np.arange(S)[::-1].copy()
+            t_desc = np.asarray(timesteps)[order].astype(np.float32)
+            # evaluation k runs at: t_0, then (x~, t_next = t_1) for the Euler corrector, then t_1, t_2, ...
+            t_eval = np.concatenate([t_desc[:1], t_desc[min(1, S - 1):min(1, S - 1) + 1], t_desc[1:]])
+            assert t_eval.shape[0] == S + 1
+            plan.t_rows.copy_(torch.as_tensor(t_eval))
+            plan.load_context(c_cross)
+            st.coefs[:S].copy_(ddim_coefficient_table(self.ddim_alphas, self.ddim_alphas_prev, self.ddim_sigmas,
+                                                      self.ddim_sqrt_one_minus_alphas, order))
+            plan.step.zero_()
+            plan.prep.run()
+            intermediates = {"x_inter": [st.x.clone()], "pred_x0": [st.x.clone()]}
+            print(f"Running PLMS Sampling with {S} timesteps")
+            for k in range(S + 1):
+                st.launch(False, cfg_scale)
+                if k == 0:
+                    continue  # predictor evaluation of the first step
+                i = k - 1
+                index = S - i - 1
+                if callback:
+                    callback(i)
+                if img_callback:
+                    img_callback(st.pred_x0.clone(), i)
+                if index % log_every_t == 0 or index == S - 1:
+                    intermediates["x_inter"].append(st.x.clone())
+                    intermediates["pred_x0"].append(st.pred_x0.clone())
+            return st.x.clone(), intermediates
 
     @torch.no_grad()
     def p_sample_plms(self, x, c, t, index, repeat_noise=False, use_original_steps=False, quantize_denoised=False,
