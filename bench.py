@@ -272,8 +272,9 @@ def main():
         achieved = ig_flops / (ig_ms * 1e-3) / 1e12
         result["roofline"] = {
             "bound": "mfma",
-            "kernel": "igemm_ws_kernel<*> + igemm_kernel<*> + igemm_reduce_kernel (implicit-GEMM conv/linear, every "
-                      "tile config; 194 launches per UNet forward)",
+            "kernel": "igemm_ws_kernel<*> + igemm_kernel<*> + igemm_reduce[_gn]_kernel (implicit-GEMM conv/linear, every "
+                      "tile config, split-K reduce passes incl. the GroupNorm statistics they emit; 194 launches per UNet "
+                      "forward)",
             "method": "graph-replay difference: (forward) - (forward without the class), HIP events on the launch stream",
             "achieved": achieved, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F16_TFLOPS,
             "traffic": igemm_traffic_bytes_per_launch(),
