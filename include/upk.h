@@ -85,6 +85,7 @@ size_t upk_packed_weight_bytes(int n_rows_packed, int cin_packed, int kh, int kw
 #define UPK_F_UPSAMPLE2X 0x10  /* input is nearest-2x upsampled on the fly                   */
                                /* (openaimodel.py:116 + :107; model.py:53-56)                */
 #define UPK_F_PAD_ASYM 0x20    /* stride-2 conv with (0,1,0,1) padding (model.py:72-76)      */
+#define UPK_F_QUICKGELU 0x40   /* y = v * sigmoid(1.702 v) after bias (CLIP text MLP, hidden_act quick_gelu) */
 
 typedef struct upk_conv_desc {
   /* input: up to two NHWC fp16 sources concatenated along C (openaimodel.py:736,
@@ -187,6 +188,18 @@ int upk_attention_f16(upk_ctx* ctx, const void* q, int ldq, long long q_batch_st
                       const void* k, int ldk, long long k_batch_stride, const void* vt, int vt_ld,
                       void* out, int ldo, long long o_batch_stride, int batch, int heads, int n_q,
                       int n_kv, int d, float scale, upk_stream stream);
+
+/* Causal self-attention (n_q == n_kv == n, key j visible to query i iff j <= i): the CLIP text transformer of the
+ * conditioning stage (ldm/modules/encoders/modules.py:137-162 -> transformers CLIPTextModel). */
+int upk_attention_causal_f16(upk_ctx* ctx, const void* q, int ldq, long long q_batch_stride,
+                             const void* k, int ldk, long long k_batch_stride, const void* vt, int vt_ld,
+                             void* out, int ldo, long long o_batch_stride, int batch, int heads, int n,
+                             int d, float scale, upk_stream stream);
+
+/* out[r, :] = tok_emb[ids[r], :] + pos_emb[r % seq, :]  (fp16 tables [vocab, dim] / [seq, dim], fp16 out [rows, ld]):
+ * CLIPTextEmbeddings.  ids outside [0, vocab) are an error the kernel cannot report: validate on the host. */
+int upk_embed_tokens_f16(upk_ctx* ctx, const int32_t* ids, const void* tok_emb, const void* pos_emb, int rows,
+                         int seq, int dim, int vocab, void* out, int ld_out, upk_stream stream);
 
 /* ------------------------------------------------------------------ */
 /* Normalisation (wavefront reductions, fp32 statistics).               */

@@ -21,12 +21,13 @@ SYMBOLS = [
     "upk_attention_f16", "upk_groupnorm_nhwc_f16", "upk_groupnorm_apply_nhwc_f16", "upk_groupnorm_ws_bytes",
     "upk_layernorm_f16", "upk_timestep_embed_f16",
     "upk_nchw_f32_to_nhwc_f16", "upk_nhwc_f16_to_nchw_f32", "upk_f32_to_f16", "upk_ddim_step_f32",
-    "upk_ddim_step_cfg_f32", "upk_plms_step_f32",
+    "upk_ddim_step_cfg_f32", "upk_plms_step_f32", "upk_attention_causal_f16", "upk_embed_tokens_f16",
     "upk_advance_step", "upk_graph_begin", "upk_graph_end", "upk_graph_launch", "upk_graph_destroy",
     "upk_prof_enable", "upk_prof_collect",
 ]
 
 F_SILU, F_GEGLU, F_OUT_F32, F_OUT_NCHW_F32, F_UPSAMPLE2X, F_PAD_ASYM = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
+F_QUICKGELU = 0x40
 NUM_CLASSES = 5
 CLASS_NAMES = ["igemm", "attention", "groupnorm", "layernorm", "other"]
 
@@ -93,6 +94,9 @@ def load_library(path=None):
             "upk_conv_config_name": (C.c_char_p, [i32]),
             "upk_attention_f16": (C.c_int, [vp, vp, i32, i64, vp, i32, i64, vp, i32, vp, i32, i64,
                                             i32, i32, i32, i32, i32, f32, vp]),
+            "upk_attention_causal_f16": (C.c_int, [vp, vp, i32, i64, vp, i32, i64, vp, i32, vp, i32, i64,
+                                                   i32, i32, i32, i32, f32, vp]),
+            "upk_embed_tokens_f16": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
             "upk_groupnorm_nhwc_f16": (C.c_int, [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp,
                                                  f32, i32, vp, i32, vp, vp]),
             "upk_groupnorm_apply_nhwc_f16": (C.c_int, [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp,
@@ -194,6 +198,14 @@ class Context:
     def attention(self, q, ldq, qbs, k, ldk, kbs, vt, vt_ld, out, ldo, obs, batch, heads, n_q, n_kv, d, scale):
         self._chk(self.lib.upk_attention_f16(self.h, _ptr(q), ldq, qbs, _ptr(k), ldk, kbs, _ptr(vt), vt_ld,
                                              _ptr(out), ldo, obs, batch, heads, n_q, n_kv, d, scale, self._s()))
+
+    def attention_causal(self, q, ldq, qbs, k, ldk, kbs, vt, vt_ld, out, ldo, obs, batch, heads, n, d, scale):
+        self._chk(self.lib.upk_attention_causal_f16(self.h, _ptr(q), ldq, qbs, _ptr(k), ldk, kbs, _ptr(vt), vt_ld,
+                                                    _ptr(out), ldo, obs, batch, heads, n, d, scale, self._s()))
+
+    def embed_tokens(self, ids, tok, pos, rows, seq, dim, vocab, out, ld):
+        self._chk(self.lib.upk_embed_tokens_f16(self.h, _ptr(ids), _ptr(tok), _ptr(pos), rows, seq, dim, vocab, _ptr(out),
+                                                ld, self._s()))
 
     def groupnorm(self, x1, c1, ld1, x2, c2, ld2, batch, hw, groups, gamma, beta, eps, silu, y, ldy, ws):
         self._chk(self.lib.upk_groupnorm_nhwc_f16(self.h, _ptr(x1), c1, ld1, _ptr(x2), c2, ld2, batch, hw, groups,

@@ -28,6 +28,7 @@ struct AttnArgs {
   long qbs, kbs, obs;
   int heads, nq, nkv;
   float scale_log2;  // scale * log2(e)
+  int causal;        // key j attends to query i only if j <= i (CLIP text encoder); n_q == n_kv
 };
 
 // One K/V tile of NS*16 keys for the QT*16 queries of this wave (NS = 4 in the main loop, 2
@@ -40,7 +41,7 @@ template <int D, int QREG, int NS, int QT>
 __device__ __forceinline__ void attn_tile(const AttnArgs& a, const f16* const* qrow, const bool* q_ok,
                                           const f16x8 (*qf)[QREG ? D / 32 : 1], const f16* kbase,
                                           const f16* vbase, int kb, int g, int c, f32x4 (*o)[D / 16], float* mrun,
-                                          float* lrun) {
+                                          float* lrun, int q0) {
   constexpr int KD = D / 32;
   constexpr int DT = D / 16;
   constexpr int NC = NS / 2;  // 32-key chunks for the PV MFMAs
@@ -86,12 +87,15 @@ __device__ __forceinline__ void attn_tile(const AttnArgs& a, const f16* const* q
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
     // lane (g, c) holds keys kb + 16t + 4g + r of query c of group u
-    if (tail) {
+    if (tail || a.causal) {
+      const int qlim = a.causal ? q0 + u * 16 + c : a.nkv;  // last key this query may see
 #pragma unroll
       for (int t = 0; t < NS; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (kb + 16 * t + 4 * g + r >= a.nkv) s[u][t][r] = -INFINITY;
+        for (int r = 0; r < 4; ++r) {
+          const int key = kb + 16 * t + 4 * g + r;
+          if (key >= a.nkv || key > qlim) s[u][t][r] = -INFINITY;
+        }
     }
     float mx = -INFINITY;
 #pragma unroll
@@ -174,10 +178,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
 
   int kb = 0;
   if (D <= 128) {  // 64-key tiles while they are full; the 32-key form handles the rest
-    for (; kb + 64 <= a.nkv; kb += 64)
-      attn_tile<D, QREG, 4, QT>(a, qrow, q_ok, qf, kbase, vbase, kb, g, c, o, mrun, lrun);
+    for (; kb + 64 <= (a.causal ? min(a.nkv, q0 + 16 * QT) : a.nkv); kb += 64)
+      attn_tile<D, QREG, 4, QT>(a, qrow, q_ok, qf, kbase, vbase, kb, g, c, o, mrun, lrun, q0);
   }
-  for (; kb < a.nkv; kb += 32) attn_tile<D, QREG, 2, QT>(a, qrow, q_ok, qf, kbase, vbase, kb, g, c, o, mrun, lrun);
+  // causal: keys beyond this wave's last query are never visible (and key 0 always is, so the running max is
+  // finite from the first tile on)
+  const int kend = a.causal ? min(a.nkv, q0 + 16 * QT) : a.nkv;
+  for (; kb < kend; kb += 32) attn_tile<D, QREG, 2, QT>(a, qrow, q_ok, qf, kbase, vbase, kb, g, c, o, mrun, lrun, q0);
 
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
@@ -344,10 +351,9 @@ __global__ __launch_bounds__(256) void attn_lds_kernel(const AttnArgs a) {
 
 }  // namespace
 
-extern "C" int upk_attention_f16(upk_ctx* ctx, const void* q, int ldq, long long qbs, const void* k, int ldk,
-                                 long long kbs, const void* vt, int vt_ld, void* out, int ldo, long long obs,
-                                 int batch, int heads, int n_q, int n_kv, int d, float scale,
-                                 upk_stream stream_) {
+static int attention_impl(upk_ctx* ctx, const void* q, int ldq, long long qbs, const void* k, int ldk, long long kbs,
+                          const void* vt, int vt_ld, void* out, int ldo, long long obs, int batch, int heads, int n_q,
+                          int n_kv, int d, float scale, int causal, upk_stream stream_) {
   if (!ctx) return UPK_EINVAL;
   if (!q || !k || !vt || !out) return upk_fail(ctx, UPK_EINVAL, "attention: null pointer");
   if (batch <= 0 || heads <= 0 || n_q <= 0 || n_kv <= 0) return upk_fail(ctx, UPK_EINVAL, "attention: empty");
@@ -370,13 +376,15 @@ extern "C" int upk_attention_f16(upk_ctx* ctx, const void* q, int ldq, long long
   a.nq = n_q;
   a.nkv = n_kv;
   a.scale_log2 = scale * 1.4426950408889634f;
+  a.causal = causal;
+  if (causal && n_q != n_kv) return upk_fail(ctx, UPK_EINVAL, "attention: causal needs n_q == n_kv");
   // two 16-query groups per wave when there are enough queries to keep every CU busy
   const int qt = (d <= 128 && (long)((n_q + 127) / 128) * batch * heads >= 2L * ctx->num_cus) ? 2 : 1;
   dim3 grid((n_q + 64 * qt - 1) / (64 * qt), batch * heads), block(256);
   upk_prof_scope prof(ctx, UPK_CLS_ATTN, stream);
   // long self-attention sequences: K / V^T tiles shared through LDS (whole 64-key tiles only)
   static const bool lds_off = getenv("UPK_ATTN_DIRECT") != nullptr;
-  if (!lds_off && (d == 32 || d == 64) && n_kv >= 256 && (n_kv & 63) == 0 && (vt_ld & 7) == 0) {
+  if (!lds_off && !causal && (d == 32 || d == 64) && n_kv >= 256 && (n_kv & 63) == 0 && (vt_ld & 7) == 0) {
     if (d == 32) {
       if (qt == 2) hipLaunchKernelGGL((attn_lds_kernel<32, 2>), grid, block, 0, stream, a);
       else hipLaunchKernelGGL((attn_lds_kernel<32, 1>), grid, block, 0, stream, a);
@@ -401,4 +409,17 @@ extern "C" int upk_attention_f16(upk_ctx* ctx, const void* q, int ldq, long long
   }
 #undef UPK_ATTN
   return upk_check_launch(ctx, "attention");
+}
+
+extern "C" int upk_attention_f16(upk_ctx* ctx, const void* q, int ldq, long long qbs, const void* k, int ldk,
+                                 long long kbs, const void* vt, int vt_ld, void* out, int ldo, long long obs,
+                                 int batch, int heads, int n_q, int n_kv, int d, float scale, upk_stream stream) {
+  return attention_impl(ctx, q, ldq, qbs, k, ldk, kbs, vt, vt_ld, out, ldo, obs, batch, heads, n_q, n_kv, d, scale, 0,
+                        stream);
+}
+
+extern "C" int upk_attention_causal_f16(upk_ctx* ctx, const void* q, int ldq, long long qbs, const void* k, int ldk,
+                                        long long kbs, const void* vt, int vt_ld, void* out, int ldo, long long obs,
+                                        int batch, int heads, int n, int d, float scale, upk_stream stream) {
+  return attention_impl(ctx, q, ldq, qbs, k, ldk, kbs, vt, vt_ld, out, ldo, obs, batch, heads, n, n, d, scale, 1, stream);
 }

@@ -162,6 +162,10 @@ struct Epi {
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = upk_silu(v[k]);
     }
+    if (flags & UPK_F_QUICKGELU) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = v[k] / (1.0f + __expf(-1.702f * v[k]));
+    }
     if (to_vt) {
       const int cc = n - a.vt_from;  // = h * dhead + d  ->  row (h*dhead + d) of this sample's V^T
       f16* dst = a.vt + r.vt_off + (unsigned)cc * (unsigned)a.vt_ld;
@@ -211,10 +215,12 @@ struct Epi {
   //          the zero page instead of being branched around;
   //   geglu: (acc_v + b_v) * gelu(acc_g + b_g) -> fp16.
   static __host__ __device__ __forceinline__ bool plain(const IgemmArgs& a) {
-    return !(a.flags & (UPK_F_GEGLU | UPK_F_SILU | UPK_F_OUT_F32 | UPK_F_OUT_NCHW_F32)) && !a.vt && !(a.n_out & 3);
+    return !(a.flags & (UPK_F_GEGLU | UPK_F_SILU | UPK_F_QUICKGELU | UPK_F_OUT_F32 | UPK_F_OUT_NCHW_F32)) && !a.vt &&
+           !(a.n_out & 3);
   }
   static __device__ __forceinline__ bool plain_geglu(const IgemmArgs& a) {
-    return (a.flags & (UPK_F_GEGLU | UPK_F_SILU | UPK_F_OUT_F32 | UPK_F_OUT_NCHW_F32)) == UPK_F_GEGLU && !a.vt &&
+    return (a.flags & (UPK_F_GEGLU | UPK_F_SILU | UPK_F_QUICKGELU | UPK_F_OUT_F32 | UPK_F_OUT_NCHW_F32)) == UPK_F_GEGLU &&
+           !a.vt &&
            !a.rowvec && !a.res && !(a.n_out & 3);
   }
   struct Plain {

@@ -273,6 +273,24 @@ __global__ void plms_step_kernel(float* x, const float* eps, const float* coefs,
   }
 }
 
+// CLIPTextEmbeddings: one thread per 8 channels
+__global__ void embed_tokens_kernel(const int* ids, const f16* tok, const f16* pos, int rows, int seq, int dim, int vocab,
+                                    f16* out, int ld) {
+  const int vpr = dim >> 3;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)rows * vpr) return;
+  const int r = (int)(idx / vpr);
+  const int v = (int)(idx - (long)r * vpr);
+  int id = ids[r];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const f16x8 a = *(const f16x8*)(tok + (long)id * dim + v * 8);
+  const f16x8 b = *(const f16x8*)(pos + (long)(r % seq) * dim + v * 8);
+  f16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (f16)((float)a[j] + (float)b[j]);
+  *(f16x8*)(out + (long)r * ld + v * 8) = o;
+}
+
 __global__ void advance_step_kernel(int* step) { *step += 1; }
 
 }  // namespace
@@ -358,6 +376,19 @@ extern "C" int upk_plms_step_f32(upk_ctx* ctx, float* x, const float* eps, const
   hipLaunchKernelGGL(plms_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x, eps,
                      coefs, step, hist, pred_x0, (f16*)xin, ld_xin, c, hw, n, cfg ? 2 : 1, cfg_scale);
   return upk_check_launch(ctx, "plms_step");
+}
+
+extern "C" int upk_embed_tokens_f16(upk_ctx* ctx, const int32_t* ids, const void* tok_emb, const void* pos_emb, int rows,
+                                    int seq, int dim, int vocab, void* out, int ld_out, upk_stream stream_) {
+  if (!ctx) return UPK_EINVAL;
+  if (!ids || !tok_emb || !pos_emb || !out || rows <= 0 || seq <= 0 || dim <= 0 || (dim & 7) || vocab <= 0 ||
+      ld_out < dim || (ld_out & 7))
+    return upk_fail(ctx, UPK_EINVAL, "embed_tokens: bad args (dim and ld_out must be multiples of 8)");
+  const long n = (long)rows * (dim >> 3);
+  upk_prof_scope prof(ctx, UPK_CLS_OTHER, (hipStream_t)stream_);
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, ids,
+                     (const f16*)tok_emb, (const f16*)pos_emb, rows, seq, dim, vocab, (f16*)out, ld_out);
+  return upk_check_launch(ctx, "embed_tokens");
 }
 
 extern "C" int upk_advance_step(upk_ctx* ctx, int32_t* step, upk_stream stream_) {
