@@ -201,6 +201,17 @@ int upk_attention_causal_f16(upk_ctx* ctx, const void* q, int ldq, long long q_b
 int upk_embed_tokens_f16(upk_ctx* ctx, const int32_t* ids, const void* tok_emb, const void* pos_emb, int rows,
                          int seq, int dim, int vocab, void* out, int ld_out, upk_stream stream);
 
+/* CLIP image tower (ldm/modules/encoders/modules.py:234-256 -> clip.model.VisionTransformer):
+ * patch embedding = upk_patchify_nchw_f32_f16 (non-overlapping p x p patches of an fp32 NCHW image -> fp16 rows
+ * [batch*(H/p)*(W/p), ld_out], k = c*p*p + py*p + px, zero padded) followed by a plain upk_gemm_f16 with the
+ * Conv2d(3, width, p, stride p) weight flattened; upk_vit_assemble_f16 prepends the class token and adds the
+ * positional embedding: out[n, 0] = class_emb + pos[0], out[n, 1 + j] = patch_emb[n, j] + pos[1 + j]. */
+int upk_patchify_nchw_f32_f16(upk_ctx* ctx, const float* x, int batch, int c, int h, int w, int patch, void* out,
+                              int ld_out, upk_stream stream);
+int upk_vit_assemble_f16(upk_ctx* ctx, const void* patch_emb, int ld_patch, const float* class_emb,
+                         const float* pos_emb, int batch, int npatch, int dim, void* out, int ld_out,
+                         upk_stream stream);
+
 /* ------------------------------------------------------------------ */
 /* Normalisation (wavefront reductions, fp32 statistics).               */
 /* ------------------------------------------------------------------ */

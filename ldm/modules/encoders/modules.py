@@ -1,31 +1,22 @@
-"""ldm.modules.encoders.modules — conditioning encoders.
+"""ldm.modules.encoders.modules — the CLIP conditioning encoders on the HIP kernels.
 
-* FrozenCLIPEmbedder (modules.py:137-162): the CLIP text tower runs on the HIP kernels
-  (upgpt_amd/clip_text.py); its tokenizer files are not available offline, so `encode(text)` needs them on disk
-  and `encode_tokens(ids)` takes token ids.
-* The CLIP image embedder (modules.py:234-256) is not built yet: the name resolves so that bbox.yaml instantiates;
-  calling it explains what to do instead — feed precomputed embeddings through DummyModel, exactly as the
-  reference's own InferenceModel does (ldm/data/generate_utils.py:142-144)."""
+* FrozenCLIPEmbedder (modules.py:137-162): CLIP text tower (upgpt_amd/clip_text.py); its tokenizer files are not
+  available offline, so `encode(text)` needs them on disk and `encode_tokens(ids)` takes token ids.
+* FrozenClipImageEmbedder2 (modules.py:234-256): CLIP ViT-L/14 image tower (upgpt_amd/clip_image.py),
+  [b, n, 3, 224, 224] pre-processed crops -> [b, n, 768].
+* FrozenCLIPTextEmbedder (the `clip`-package text encoder, unused by the UPGPT configs) is not built."""
 from torch import nn
 
+from upgpt_amd.clip_image import CLIPVisual, FrozenClipImageEmbedder2  # noqa: F401
 from upgpt_amd.clip_text import CLIPTextTransformer, FrozenCLIPEmbedder  # noqa: F401
 
 
-class _ExternalEncoder(nn.Module):
+class FrozenCLIPTextEmbedder(nn.Module):
     def __init__(self, *args, **kwargs):
         super().__init__()
 
     def forward(self, *a, **k):
-        raise NotImplementedError(
-            "%s (CLIP image tower) is not part of upgpt_amd yet: pass precomputed [B, 9, 768] embeddings and set the "
-            "stage's target to ldm.modules.poses.poses.DummyModel" % type(self).__name__)
+        raise NotImplementedError("FrozenCLIPTextEmbedder (clip-package text encoder) is not used by the UPGPT configs and "
+                                  "is not part of upgpt_amd; FrozenCLIPEmbedder is")
 
     encode = forward
-
-
-class FrozenClipImageEmbedder2(_ExternalEncoder):
-    pass
-
-
-class FrozenCLIPTextEmbedder(_ExternalEncoder):
-    pass

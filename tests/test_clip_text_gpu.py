@@ -100,3 +100,45 @@ def test_clip_text_tower_vs_transformers_golden():
         enc.encode(["a photo"])  # tokenizer files are not available offline: a clear error, not a fallback
     with pytest.raises(ValueError):
         enc.encode_tokens(torch.full((2, 77), 49408))
+
+
+def test_vit_patchify_and_assemble(ctx):
+    N, C, H, W, p, dim = 2, 3, 28, 42, 14, 64
+    x = rnd(N, C, H, W)
+    ld = 608
+    out = torch.full((N * (H // p) * (W // p), ld), float("nan"), device=DEV, dtype=torch.float16)
+    ctx._chk(ctx.lib.upk_patchify_nchw_f32_f16(ctx.h, x.data_ptr(), N, C, H, W, p, out.data_ptr(), ld, ctx._s()))
+    torch.cuda.synchronize()
+    ref = F.unfold(x, kernel_size=p, stride=p).transpose(1, 2).reshape(-1, C * p * p)  # k = c*p*p + py*p + px
+    assert torch.equal(out[:, :C * p * p], ref.half()) and (out[:, C * p * p:] == 0).all()
+    npatch = (H // p) * (W // p)
+    pe = rnd(N * npatch, dim, seed=1).half()
+    cls, pos = rnd(dim, seed=2), rnd(npatch + 1, dim, seed=3)
+    tok = torch.zeros(N * (npatch + 1), dim, device=DEV, dtype=torch.float16)
+    ctx._chk(ctx.lib.upk_vit_assemble_f16(ctx.h, pe.data_ptr(), dim, cls.data_ptr(), pos.data_ptr(), N, npatch, dim,
+                                          tok.data_ptr(), dim, ctx._s()))
+    torch.cuda.synchronize()
+    ref = torch.cat([cls.expand(N, 1, dim), pe.float().view(N, npatch, dim)], 1) + pos
+    assert torch.equal(tok.view(N, npatch + 1, dim), ref.half())
+
+
+def test_clip_image_tower_vs_transformers_golden():
+    import zlib
+    from ldm.modules.encoders.modules import FrozenClipImageEmbedder2
+    g = np.load(os.path.join(G, "clip_image.npz"))
+    enc = FrozenClipImageEmbedder2()
+    sd = {k: synth.synth_tensor("extra_cond_models.0." + k, tuple(v.shape)) for k, v in enc.state_dict().items()}
+    assert len(sd) == int(g["n_keys"]) and "model.visual.transformer.resblocks.23.mlp.c_proj.weight" in sd
+    enc.load_state_dict(sd)
+    enc = enc.cuda()
+    gen = torch.Generator(device="cpu").manual_seed(777)
+    x = torch.randn(1, 3, 3, 224, 224, generator=gen)
+    assert (zlib.crc32(x.numpy().tobytes()) & 0xFFFFFFFF) == int(g["x_crc"]), "torch.randn stream changed"
+    z = enc(x.cuda())
+    ref = torch.as_tensor(g["image_embeds"])
+    assert z.shape == (1, 3, 768) and torch.isfinite(z).all()
+    err = (z.cpu() - ref).abs()
+    rel = float(err.max()) / float(ref.abs().max())
+    print("CLIP image tower vs transformers golden: mse %.3e, max err %.3e (|ref| mean %.3f, max rel %.3e)" % (
+        float((err ** 2).mean()), float(err.max()), float(g["abs_mean"]), rel))
+    assert float((err ** 2).mean()) < 1e-3 and rel < 3e-2

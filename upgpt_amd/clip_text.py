@@ -15,6 +15,8 @@ MLP 768 -> 3072 -> 768 with quick_gelu) -> final LayerNorm; the embedder returns
   available offline: `encode(text)` needs `transformers.CLIPTokenizer` files on disk, `encode_tokens(ids)` takes the
   int token ids directly (the oracle boundary for this stage).
 """
+import os
+
 import torch
 from torch import nn
 
@@ -92,7 +94,7 @@ class _TextPlan(Emitter):
         fn_l = self.lib.upk_layernorm_f16
         al = (x.t.data_ptr(), x.ld, M, d, g.data_ptr(), b_.data_ptr(), eps, self.out.t.data_ptr(), self.out.ld)
         P.add(lambda s: chk(fn_l(h, *al, s)), x, g, b_, self.out, cls="layernorm")
-        self.apply_tuning()
+        self.apply_tuning(tune_missing=os.environ.get("UPGPT_AUTOTUNE", "0") == "1")
 
     def run(self, ids):
         if tuple(ids.shape) != (self.B, self.cfg["max_position_embeddings"]):

@@ -273,6 +273,41 @@ __global__ void plms_step_kernel(float* x, const float* eps, const float* coefs,
   }
 }
 
+// ViT patch embedding, step 1 (CLIP image tower, Conv2d(3, width, patch, stride = patch, bias = False)): the
+// non-overlapping patches of an fp32 NCHW image become the rows of an fp16 matrix [N * (H/p) * (W/p), ld] with
+// k = c * p * p + py * p + px (the conv weight's own [out][c][py][px] flattening), zero padded to ld.
+__global__ void patchify_kernel(const float* x, int c, int h, int w, int p, f16* out, int ld, long rows) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * ld) return;
+  const long row = idx / ld;
+  const int k = (int)(idx - row * ld);
+  const int gw = w / p, gh = h / p;
+  const int n = (int)(row / (gh * gw));
+  const int pr = (int)(row - (long)n * gh * gw);
+  const int gy = pr / gw, gx = pr - gy * gw;
+  float v = 0.f;
+  if (k < c * p * p) {
+    const int ch = k / (p * p);
+    const int r = k - ch * p * p;
+    const int py = r / p, px = r - py * p;
+    v = x[(((long)n * c + ch) * h + gy * p + py) * w + gx * p + px];
+  }
+  out[idx] = (f16)v;
+}
+
+// ViT token assembly: out[n, 0] = class_embedding + pos[0]; out[n, 1 + j] = patch_emb[n, j] + pos[1 + j]
+__global__ void vit_assemble_kernel(const f16* patch, int ldp, const float* cls, const float* pos, int npatch, int dim,
+                                    f16* out, int ld, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int d = (int)(idx % dim);
+  const long t = idx / dim;
+  const int tok = (int)(t % (npatch + 1));
+  const long n = t / (npatch + 1);
+  const float v = tok == 0 ? cls[d] : (float)patch[(n * npatch + tok - 1) * ldp + d];
+  out[t * ld + d] = (f16)(v + pos[(long)tok * dim + d]);
+}
+
 // CLIPTextEmbeddings: one thread per 8 channels
 __global__ void embed_tokens_kernel(const int* ids, const f16* tok, const f16* pos, int rows, int seq, int dim, int vocab,
                                     f16* out, int ld) {
@@ -376,6 +411,33 @@ extern "C" int upk_plms_step_f32(upk_ctx* ctx, float* x, const float* eps, const
   hipLaunchKernelGGL(plms_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x, eps,
                      coefs, step, hist, pred_x0, (f16*)xin, ld_xin, c, hw, n, cfg ? 2 : 1, cfg_scale);
   return upk_check_launch(ctx, "plms_step");
+}
+
+extern "C" int upk_patchify_nchw_f32_f16(upk_ctx* ctx, const float* x, int batch, int c, int h, int w, int patch, void* out,
+                                        int ld_out, upk_stream stream_) {
+  if (!ctx) return UPK_EINVAL;
+  if (!x || !out || batch <= 0 || c <= 0 || patch <= 0 || h % patch || w % patch || ld_out < c * patch * patch)
+    return upk_fail(ctx, UPK_EINVAL, "patchify: bad args (H, W must be multiples of the patch, ld_out >= c*p*p)");
+  const long rows = (long)batch * (h / patch) * (w / patch);
+  const long n = rows * ld_out;
+  upk_prof_scope prof(ctx, UPK_CLS_OTHER, (hipStream_t)stream_);
+  hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x, c, h, w,
+                     patch, (f16*)out, ld_out, rows);
+  return upk_check_launch(ctx, "patchify");
+}
+
+extern "C" int upk_vit_assemble_f16(upk_ctx* ctx, const void* patch_emb, int ld_patch, const float* class_emb,
+                                    const float* pos_emb, int batch, int npatch, int dim, void* out, int ld_out,
+                                    upk_stream stream_) {
+  if (!ctx) return UPK_EINVAL;
+  if (!patch_emb || !class_emb || !pos_emb || !out || batch <= 0 || npatch <= 0 || dim <= 0 || ld_patch < dim ||
+      ld_out < dim)
+    return upk_fail(ctx, UPK_EINVAL, "vit_assemble: bad args");
+  const long total = (long)batch * (npatch + 1) * dim;
+  upk_prof_scope prof(ctx, UPK_CLS_OTHER, (hipStream_t)stream_);
+  hipLaunchKernelGGL(vit_assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
+                     (const f16*)patch_emb, ld_patch, class_emb, pos_emb, npatch, dim, (f16*)out, ld_out, total);
+  return upk_check_launch(ctx, "vit_assemble");
 }
 
 extern "C" int upk_embed_tokens_f16(upk_ctx* ctx, const int32_t* ids, const void* tok_emb, const void* pos_emb, int rows,
