@@ -142,3 +142,34 @@ def test_clip_image_tower_vs_transformers_golden():
     print("CLIP image tower vs transformers golden: mse %.3e, max err %.3e (|ref| mean %.3f, max rel %.3e)" % (
         float((err ** 2).mean()), float(err.max()), float(g["abs_mean"]), rel))
     assert float((err ** 2).mean()) < 1e-3 and rel < 3e-2
+
+
+def test_log_images_with_image_tower_as_style_stage():
+    """End to end through the reference's caller surface: LatentDiffusion.log_images with the style stage being a real
+    (small) CLIP image tower fed with [B, 9, 3, 224, 224] crops — cond assembly text | styles | smpl as ddpm.py:734-739."""
+    import upgpt_amd
+    from upgpt_amd.clip_image import FrozenClipImageEmbedder2
+    from upgpt_amd.ddim import DDIMSampler
+    model = upgpt_amd.build_model("tiny")
+    synth.fill_module_(model)
+    enc = FrozenClipImageEmbedder2(width=256, layers=2, heads=4, output_dim=768)
+    enc.load_state_dict({k: synth.synth_tensor("extra_cond_models.0." + k, tuple(v.shape))
+                         for k, v in enc.state_dict().items()})
+    model.extra_cond_models[0] = enc
+    model = model.cuda()
+    B = 2
+    g0 = torch.Generator().manual_seed(5)
+    batch = {"image": torch.rand(B, 256, 192, 3, generator=g0) * 2 - 1, "txt": torch.randn(B, 77, 768, generator=g0),
+             "styles": torch.randn(B, 9, 3, 224, 224, generator=g0), "smpl": 0.5 * torch.randn(B, 1, 85, generator=g0),
+             "person_mask": synth.person_mask(B, 32, 24)}
+    log = model.log_images(batch, N=B, ddim_steps=4, ddim_eta=0.0, seed=3, use_ema=True)
+    assert log["samples"].shape == (B, 3, 256, 192) and torch.isfinite(log["samples"]).all()
+    styles = enc(batch["styles"].cuda())
+    assert styles.shape == (B, 9, 768)
+    ctx = torch.cat([batch["txt"].cuda(), styles, model.extra_cond_models[1](batch["smpl"].cuda())], 1)
+    torch.manual_seed(3)
+    x_T = torch.randn((1, 4, 32, 24), device="cuda").repeat(B, 1, 1, 1)
+    with model.ema_scope():
+        z, _ = DDIMSampler(model).sample(4, B, (4, 32, 24), {"c_crossattn": ctx, "c_concat": [batch["person_mask"].cuda()]},
+                                         eta=0.0, x_T=x_T, verbose=False)
+    assert torch.equal(model.decode_first_stage(z), log["samples"])
