@@ -182,6 +182,44 @@ def cpu_baseline(hw, ddim_steps, batch):
             "unet_fwd_s": t_fwd, "decode_b1_s": t_dec}
 
 
+def encoders_secondary(model, wl, dev):
+    """BASELINE configs[2] with the conditioning computed on the device: token ids [B, 77] -> CLIP text tower, style
+    crops [B, 9, 3, 224, 224] -> CLIP ViT-L/14 image tower, SMPL [B, 1, 85] -> LinearProject, concatenated to the
+    [B, 87, 768] context (ddpm.py:734-739), then the main workload (50-step DDIM + decode)."""
+    from upgpt_amd import synth
+    from upgpt_amd.clip_image import FrozenClipImageEmbedder2
+    from upgpt_amd.clip_text import FrozenCLIPEmbedder
+    txt = FrozenCLIPEmbedder()
+    txt.load_state_dict({k: synth.synth_tensor("cond_stage_model." + k, tuple(v.shape)) for k, v in txt.state_dict().items()})
+    img = FrozenClipImageEmbedder2()
+    img.load_state_dict({k: synth.synth_tensor("extra_cond_models.0." + k, tuple(v.shape))
+                         for k, v in img.state_dict().items()})
+    txt, img = txt.cuda(), img.cuda()
+    g = torch.Generator(device="cpu").manual_seed(99)
+    B = wl.B
+    ids = torch.randint(0, 49408, (B, 77), generator=g)
+    crops = torch.randn(B, 9, 3, 224, 224, generator=g).cuda()
+    smpl = (0.5 * torch.randn(B, 1, 85, generator=g)).cuda()
+    pose = model.extra_cond_models[1]
+
+    def run():
+        ctx = torch.cat([txt.encode_tokens(ids), img(crops), pose(smpl)], 1)
+        with model.ema_scope():
+            z, _ = wl.sampler.sample(wl.S, B, (4,) + tuple(wl.hw), {"c_crossattn": ctx, "c_concat": wl.cond["c_concat"]},
+                                     eta=0.0, x_T=wl.x_T, verbose=False, log_every_t=10 ** 6)
+        return model.decode_first_stage(z)
+
+    def enc_only():
+        return torch.cat([txt.encode_tokens(ids), img(crops), pose(smpl)], 1)
+
+    quiet(run)
+    dt, out = timed(lambda: quiet(run), 2, dev)
+    te, _ = timed(enc_only, 3, dev)
+    assert torch.isfinite(out).all()
+    return {"value": B * 2 / dt, "unit": "images/s", "ms_per_step": dt / 2 * 1e3, "encoders_ms": te / 3 * 1e3,
+            "note": "token ids / pre-processed crops in (tokenizer and crop pre-processing stay on the host)"}
+
+
 def upscale_secondary(ddim_steps, dev, batch=4, hw=(64, 64)):
     """BASELINE configs[4] as worded there: the upscale model (models/upgpt/upscale/config.yaml) at bs=4 on a 64x64
     latent, 50-step DDIM; UNet sampling loop only (its kl-f4 first stage is outside the path)."""
@@ -222,6 +260,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--cfg", type=float, default=0.0,
                     help="also time the main workload with classifier-free guidance at this scale (UNet on 2*B rows)")
+    ap.add_argument("--encoders", action="store_true",
+                    help="also time BASELINE configs[2] end to end: CLIP text tower (8 prompts) + CLIP ViT-L/14 image tower "
+                         "(8 x 9 style crops) + SMPL projection -> 50-step DDIM -> decode")
     ap.add_argument("--upscale", action="store_true",
                     help="also time BASELINE configs[4]: the upscale UNet, bs=4, 64x64 latent, 50-step DDIM (UNet loop only)")
     args = ap.parse_args()
@@ -308,6 +349,8 @@ def main():
             dtc, _ = timed(lambda: quiet(run_cfg), 2, dev)
             result["config_cfg"] = {"value": args.batch * 2 / dtc, "unit": "images/s", "guidance_scale": args.cfg,
                                     "ms_per_step": dtc / 2 * 1e3, "unet_rows": 2 * args.batch}
+        if args.encoders and world == 1:
+            result["config_full_cond_with_encoders"] = encoders_secondary(model, wl, dev)
         if args.upscale and world == 1:
             result["config_upscale_bs4_64x64"] = upscale_secondary(args.ddim_steps, dev)
         if not args.no_cpu_baseline and world == 1:
