@@ -18,7 +18,10 @@ import os
 import sys
 import time
 
-import torch
+# multi-process GPU work (RCCL) on this host needs dmabuf IPC; harmless for N = 1
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
