@@ -64,7 +64,7 @@ def make_desc(ctx, x1, w, bias, y, *, x2=None, stride=1, flags=0, n_out=None, re
         d.step = step.data_ptr()
     d.y = y.data_ptr(); d.ldy = y.shape[-1]
     d.flags = flags
-    d._keep = (wp, bp)
+    d._keep = (wp, bp, x1, x2, residual, rowvec, step, y)  # the descriptor holds raw pointers only
     return d
 
 
@@ -114,6 +114,78 @@ def test_conv_all_configs_and_splitk(ctx):
                 check(y.permute(0, 3, 1, 2), ref)
     finally:
         ctx.conv_override(-1, 0)
+
+
+def test_conv_randomised_shapes_configs_and_epilogues(ctx):
+    """Seeded sweep over ragged shapes (M not a tile multiple, N not a multiple of 16, 1x1 / 3x3, stride 2, upsample,
+    concat), random tile configurations / split-K factors and epilogue combinations (bias, residual, timestep row
+    vector, SiLU / quick-GELU, fp32 output, GroupNorm by-product) against F.conv2d.  Infeasible (config, split-K)
+    pairs are refused by the library and skipped; everything that runs must be right."""
+    g = torch.Generator(device="cpu").manual_seed(20240928)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    ncfg = ctx.lib.upk_conv_num_configs()
+    ran = 0
+    for case in range(60):
+        ks = 3 if ri(0, 1) else 1
+        stride = 2 if (ks == 3 and ri(0, 4) == 0) else 1
+        ups = ks == 3 and stride == 1 and ri(0, 5) == 0
+        B, H, W = ri(1, 3), ri(2, 13), ri(2, 13)
+        c1 = 32 * ri(1, 6)
+        c2 = 32 * ri(1, 3) if ri(0, 3) == 0 else 0
+        cout = 4 * ri(1, 60)
+        xa, xb = rnd(B, c1, H, W, seed=case), (rnd(B, c2, H, W, seed=1000 + case) if c2 else None)
+        w = rnd(cout, c1 + c2, ks, ks, scale=1 / math.sqrt(ks * ks * (c1 + c2)), seed=2000 + case)
+        b = rnd(cout, scale=0.1, seed=3000 + case) if ri(0, 3) else None
+        ref = conv_ref(torch.cat([xa, xb], 1) if c2 else xa, w, b, stride=stride, ups=ups)
+        Ho, Wo = ref.shape[2:]
+        flags = L.F_UPSAMPLE2X if ups else 0
+        rv = step = None
+        if ri(0, 3) == 0:
+            rv = rnd(3, B, cout, seed=4000 + case)
+            step = torch.tensor([ri(0, 2)], dtype=torch.int32, device=DEV)
+            ref = ref + rv[int(step)][:, :, None, None]
+        act = ri(0, 5)
+        if act == 0:
+            flags |= L.F_SILU
+            ref = F.silu(ref)
+        elif act == 1:
+            flags |= L.F_QUICKGELU
+            ref = ref * torch.sigmoid(1.702 * ref)
+        res = None
+        if ri(0, 2) == 0:
+            res = rnd(B, cout, Ho, Wo, seed=5000 + case)
+            ref = ref + res.half().float()
+        f32 = ri(0, 5) == 0
+        y = torch.zeros(B, Ho, Wo, cout, device=DEV, dtype=torch.float32 if f32 else torch.float16)
+        if f32:
+            flags |= L.F_OUT_F32
+        d = make_desc(ctx, nhwc16(xa), w, b, y, x2=nhwc16(xb) if c2 else None, stride=stride, flags=flags,
+                      residual=nhwc16(res) if res is not None else None, rowvec=rv, rv_bs=cout, rv_ss=B * cout, step=step)
+        sws = None
+        if cout % 32 == 0 and ri(0, 1):
+            sws = torch.zeros(ctx.gn_stats_floats(B, d.n_pad), device=DEV)
+            d.gn_stats_ws, d.gn_groups = sws.data_ptr(), 32
+        for trial in range(4):
+            cfg, sk = (-1, 0) if trial == 0 else (ri(0, ncfg - 1), (1, 1, 2, 3, 4)[ri(0, 4)])
+            ctx.conv_override(cfg, sk)
+            y.zero_()
+            try:
+                ctx.conv(d)
+            except L.UpkError:
+                continue
+            finally:
+                ctx.conv_override(-1, 0)
+            torch.cuda.synchronize()
+            try:
+                check(y.permute(0, 3, 1, 2), ref, tol=2e-2)
+            except AssertionError as e:
+                raise AssertionError("case %d: ks=%d stride=%d ups=%s B=%d %dx%d c1=%d c2=%d cout=%d flags=%#x bias=%s rv=%s res=%s "
+                                     "f32=%s gn=%s cfg=%s sk=%d: %s" % (
+                                         case, ks, stride, ups, B, H, W, c1, c2, cout, flags, b is not None, rv is not None,
+                                         res is not None, f32, sws is not None,
+                                         ctx.lib.upk_conv_config_name(cfg).decode() if cfg >= 0 else "auto", sk, e)) from None
+            ran += 1
+    assert ran >= 120
 
 
 def test_conv_concat_rowvec_residual_silu(ctx):
