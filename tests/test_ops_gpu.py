@@ -463,6 +463,68 @@ def test_attention(ctx, d, nq, nkv, heads):
     check(out.view(B, nq, heads, d).transpose(1, 2), ref, tol=1e-2)
 
 
+def test_attention_and_norms_randomised(ctx):
+    """Seeded sweep: attention over ragged (n_q, n_kv) incl. the LDS-staged and the causal forms; GroupNorm over odd
+    pixel counts / two sources / group widths that straddle 16-byte vectors; LayerNorm over every supported width."""
+    g = torch.Generator(device="cpu").manual_seed(7)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    for case in range(24):
+        d, heads, B = (32, 64, 128)[ri(0, 2)], ri(1, 4), ri(1, 3)
+        nq = ri(1, 300)
+        nkv = nq if ri(0, 2) == 0 else (64 * ri(4, 6) if ri(0, 2) == 0 else ri(1, 300))
+        causal = nq == nkv and ri(0, 1) == 1
+        q = rnd(B, nq, heads * d, seed=case).half()
+        k = rnd(B, nkv, heads * d, seed=100 + case).half()
+        v = rnd(B, nkv, heads * d, seed=200 + case).half()
+        vt_ld = (nkv + 31) // 32 * 32
+        vt = torch.zeros(B, heads, d, vt_ld, device=DEV, dtype=torch.float16)
+        vt[..., :nkv] = v.view(B, nkv, heads, d).permute(0, 2, 3, 1)
+        out = torch.zeros(B, nq, heads * d, device=DEV, dtype=torch.float16)
+        a = (q, heads * d, nq * heads * d, k, heads * d, nkv * heads * d, vt, vt_ld, out, heads * d, nq * heads * d, B, heads)
+        if causal:
+            ctx.attention_causal(*a, nq, d, d ** -0.5)
+        else:
+            ctx.attention(*a, nq, nkv, d, d ** -0.5)
+        torch.cuda.synchronize()
+        qf = q.float().view(B, nq, heads, d).transpose(1, 2)
+        kf = k.float().view(B, nkv, heads, d).transpose(1, 2)
+        vf = v.float().view(B, nkv, heads, d).transpose(1, 2)
+        sc = qf @ kf.transpose(-1, -2) * d ** -0.5
+        if causal:
+            sc = sc.masked_fill(torch.ones(nq, nkv, device=DEV, dtype=torch.bool).triu(1), float("-inf"))
+        ref = torch.softmax(sc, -1) @ vf
+        got = out.view(B, nq, heads, d).transpose(1, 2).float()
+        assert torch.isfinite(got).all(), (case, d, nq, nkv, causal)
+        assert (got - ref).abs().max().item() < 1e-2 * ref.abs().max().item(), (case, d, nq, nkv, causal)
+    for case in range(16):
+        C = 32 * ri(1, 24)
+        c2 = 8 * ri(0, C // 8 - 1) if ri(0, 1) else 0
+        c1 = C - c2
+        if c1 % 8:
+            c1, c2 = C, 0
+        B, hw, silu = ri(1, 3), ri(1, 700), bool(ri(0, 1))
+        xa = (rnd(B, hw, c1, seed=300 + case) * 2 + 0.5).half()
+        xb = (rnd(B, hw, c2, seed=400 + case) - 0.3).half() if c2 else None
+        gamma, beta = 1 + 0.1 * rnd(C, seed=500 + case), 0.1 * rnd(C, seed=600 + case)
+        x = torch.cat([xa, xb], -1) if c2 else xa
+        ref = F.group_norm(x.float().permute(0, 2, 1), 32, gamma, beta, 1e-5).permute(0, 2, 1)
+        ref = F.silu(ref) if silu else ref
+        y = torch.zeros(B, hw, C, device=DEV, dtype=torch.float16)
+        ws = torch.zeros(ctx.groupnorm_ws_bytes(B, hw) // 4, device=DEV)
+        ctx.groupnorm(xa, c1, c1, xb, c2, c2, B, hw, 32, gamma, beta, 1e-5, silu, y, C, ws)
+        torch.cuda.synchronize()
+        assert (y.float() - ref).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item()), (case, c1, c2, hw)
+    for case in range(12):
+        dln, rows = 8 * ri(1, 256), ri(1, 400)
+        x = (rnd(rows, dln, seed=700 + case) * 3 + 1).half()
+        gamma, beta = 1 + 0.1 * rnd(dln, seed=800 + case), 0.1 * rnd(dln, seed=900 + case)
+        y = torch.zeros(rows, dln, device=DEV, dtype=torch.float16)
+        ctx.layernorm(x, dln, rows, dln, gamma, beta, 1e-5, y, dln)
+        torch.cuda.synchronize()
+        ref = F.layer_norm(x.float(), (dln,), gamma, beta, 1e-5)
+        assert (y.float() - ref).abs().max().item() < 1e-2 * max(1.0, ref.abs().max().item()), (case, dln, rows)
+
+
 def test_attention_online_softmax_rescale(ctx):
     """A late key with a huge score forces the running-max rescale branch."""
     B, heads, d, nq, nkv = 1, 1, 64, 16, 96
