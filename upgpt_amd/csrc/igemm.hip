@@ -33,6 +33,14 @@ enum {
   ABL_EMPTY = 0x100000,  // WS kernel returns at entry (pure launch cost of its geometry)
   ABL_TIMELINE = 0x200000,  // WS kernel: blocks 0 and gridDim.x-1 write s_memtime stamps to the workspace
 };
+// The ablation / timeline hooks are compiled in only for dev builds (UPK_CXXFLAGS=-DUPK_DEV, scripts/ablate.sh,
+// scripts/timeline*.py): even as never-taken runtime tests they cost scalar registers and instructions in the loops.
+#if defined(UPK_DEV) || defined(UPK_TIMELINE)
+#define ABL_ON(f) ((a.flags & (f)) != 0)
+#else
+#define ABL_ON(f) (false)
+#endif
+
 
 struct IgemmArgs {
   const f16* x1;
@@ -619,7 +627,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
   int cur = 0;
   for (int kc = kc0; kc < kc1; kc += KS) {
     const bool more = (kc + KS < kc1);
-    if (more && !(a.flags & ABL_NOGLOAD)) load_tiles();
+    if (more && !ABL_ON(ABL_NOGLOAD)) load_tiles();
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const f16* tA = sA + cur * A_STAGE + s * A_TILE + a_base;
@@ -629,7 +637,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
       for (int i = 0; i < MI; ++i) fa[i] = *(const f16x8*)(tA + i * 512);
 #pragma unroll
       for (int j = 0; j < NI; ++j) fb[j] = *(const f16x8*)(tB + j * 512);
-      if (!(a.flags & ABL_NOMFMA)) {
+      if (!ABL_ON(ABL_NOMFMA)) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -642,7 +650,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
         for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(fb[j]));
       }
     }
-    if (more && !(a.flags & ABL_NOLDSW)) store_tiles(cur ^ 1);
+    if (more && !ABL_ON(ABL_NOLDSW)) store_tiles(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
@@ -650,7 +658,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
   // ---- epilogue: lane (lg, lc) holds rows m = .. + lc, cols n = .. + 4*lg + r ----
   const int mw = m0 + wm * (MI * 16);
   const int nw = n0 + wn * (NI * 16);
-  if (a.flags & ABL_NOEPI) {
+  if ABL_ON(ABL_NOEPI) {
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -718,8 +726,8 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
 
   __shared__ __attribute__((aligned(16))) f16 smem[NBUF * STAGE + DUMP];
 
-  if (a.flags & ABL_EMPTY) return;
-  const bool tl = (a.flags & ABL_TIMELINE) && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && blockIdx.z == 0;
+  if ABL_ON(ABL_EMPTY) return;
+  const bool tl = ABL_ON(ABL_TIMELINE) && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && blockIdx.z == 0;
   unsigned long long* tlp = a.dbg + (blockIdx.x == 0 ? 0 : 32);
 #ifdef UPK_TIMELINE
 #define STAMP(i) do { if (tl && (threadIdx.x & 63) == 0) tlp[i] = __builtin_readcyclecounter(); } while (0)
@@ -864,7 +872,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
     for (int t = 0; t < nstages; ++t) {
       // slot (t + D) % NBUF held stage t - 1: its readers passed the barrier that ended iteration t-1
       if (issued < nstages) {
-        if (!(a.flags & ABL_NOGLOAD)) issue_stage(issued % NBUF);
+        if (!ABL_ON(ABL_NOGLOAD)) issue_stage(issued % NBUF);
         ++issued;
       }
       const int outstanding = issued - (t + 1);  // stages t+1 .. issued-1
@@ -905,7 +913,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
 #pragma unroll
     for (int s0 = 0; s0 < (KSPLIT ? KS / 4 : KS); ++s0) {
       const int s = KSPLIT ? wave + 4 * s0 : s0;  // K-split: this wave's chunks of the stage
-      if (a.flags & ABL_NOLDSW) continue;  // (ablation: no LDS reads either)
+      if ABL_ON(ABL_NOLDSW) continue;  // (ablation: no LDS reads either)
       const f16* tA = slot + s * ROWS * 32 + a_base;
       const f16* tB = slot + s * ROWS * 32 + b_base;
       f16x8 fa[MI], fb[NI];
@@ -913,7 +921,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
       for (int i = 0; i < MI; ++i) fa[i] = *(const f16x8*)(tA + i * 512);
 #pragma unroll
       for (int j = 0; j < NI; ++j) fb[j] = *(const f16x8*)(tB + j * 512);
-      if (!(a.flags & ABL_NOMFMA)) {
+      if (!ABL_ON(ABL_NOMFMA)) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -955,7 +963,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
 #pragma unroll
       for (int j = 0; j < NI; ++j) *(f32x4*)(red + ((wave * NF + i * NI + j) * 64 + lane) * 4) = acc[i][j];
     __syncthreads();  // MFMA waves only: the loader waves have already ended
-    if (a.flags & ABL_NOEPI) return;
+    if ABL_ON(ABL_NOEPI) return;
     auto frag_sum = [&](int f) {
       f32x4 v = *(const f32x4*)(red + ((0 * NF + f) * 64 + lane) * 4);
 #pragma unroll
@@ -1085,7 +1093,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
       for (int j = 0; j < NI; ++j) acc[i][j] = (acc[i][j] - mean * u[j]) * rstd;
     }
   }
-  if (a.flags & ABL_NOEPI) {
+  if ABL_ON(ABL_NOEPI) {
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
