@@ -225,14 +225,15 @@ int upk_groupnorm_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int ld1, const 
                            const float* beta, float eps, int fuse_silu, void* y, int ldy,
                            float* stats_ws, upk_stream stream);
 size_t upk_groupnorm_ws_bytes(int batch, int hw);
-/* Second half of upk_groupnorm_nhwc_f16 only: stats_ws already holds the partial sums of this tensor, left by
- * the conv launch that produced it (upk_conv_desc.gn_stats_ws): stats_mode / stats_nblk as reported by
- * upk_conv_gn_fused, stats_ld = that launch's n_pad (mode 2; single-source input only). */
+/* Second half of upk_groupnorm_nhwc_f16 only: stats_ws already holds the partial sums of x1, left by the conv
+ * launch that produced it (upk_conv_desc.gn_stats_ws): stats_mode / stats_nblk as reported by upk_conv_gn_fused,
+ * stats_ld = that launch's n_pad.  A two-source (concat) input needs mode 2 for BOTH sources: stats_ws2 /
+ * stats_nblk2 / stats_ld2 describe x2's producer (NULL / 0 / 0 for a single source). */
 int upk_groupnorm_apply_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* x2, int c2,
                                  int ld2, int batch, int hw, int groups, const float* gamma,
                                  const float* beta, float eps, int fuse_silu, void* y, int ldy,
                                  const float* stats_ws, int stats_mode, int stats_nblk, int stats_ld,
-                                 upk_stream stream);
+                                 const float* stats_ws2, int stats_nblk2, int stats_ld2, upk_stream stream);
 
 /* LayerNorm over the last dim of fp16 [rows, d] (attention.py:203-205, eps 1e-5). */
 int upk_layernorm_f16(upk_ctx* ctx, const void* x, int ldx, int rows, int d, const float* gamma,

@@ -370,7 +370,7 @@ def test_splitk_reduce_emits_groupnorm_partials(ctx, cin, cout, hw, res):
         ctx.groupnorm(y, cout, cout, None, 0, 0, B, H * W, 32, gamma, beta, 1e-5, True, full, cout, ws2)
         ctx._chk(ctx.lib.upk_groupnorm_apply_nhwc_f16(ctx.h, y.data_ptr(), cout, cout, None, 0, 0, B, H * W, 32,
                                                       gamma.data_ptr(), beta.data_ptr(), 1e-5, 1, app.data_ptr(), cout,
-                                                      sws.data_ptr(), 1, 0, n_pad, ctx._s()))
+                                                      sws.data_ptr(), 1, 0, n_pad, None, 0, 0, ctx._s()))
         torch.cuda.synchronize()
         assert torch.equal(full, app)
     # without split-K: per-(M tile, channel) partials from the epilogue (mode 2) where the tile configuration allows
@@ -389,7 +389,7 @@ def test_splitk_reduce_emits_groupnorm_partials(ctx, cin, cout, hw, res):
                 app = torch.zeros_like(y)
                 ctx._chk(ctx.lib.upk_groupnorm_apply_nhwc_f16(
                     ctx.h, y.data_ptr(), cout, cout, None, 0, 0, B, H * W, 32, gamma.data_ptr(), beta.data_ptr(), 1e-5, 1,
-                    app.data_ptr(), cout, sws.data_ptr(), 2, nblk, n_pad, ctx._s()))
+                    app.data_ptr(), cout, sws.data_ptr(), 2, nblk, n_pad, None, 0, 0, ctx._s()))
                 torch.cuda.synchronize()
                 check(y, ref)
                 full = torch.zeros_like(y)
@@ -402,6 +402,50 @@ def test_splitk_reduce_emits_groupnorm_partials(ctx, cin, cout, hw, res):
         finally:
             ctx.conv_override(-1, 0)
     assert 2 in modes
+
+
+def test_groupnorm_apply_from_two_producers_channel_partials(ctx):
+    """Decoder ResBlock input: GroupNorm over the concat [h, skip] whose two sources were produced by different unsplit
+    conv launches; both leave per-(M tile, channel) partials and the GroupNorm runs its apply pass only."""
+    B, H, W = 2, 16, 16
+    outs, descs, bufs = [], [], []
+    for (cin, cout, seed) in ((64, 448, 1), (96, 224, 2)):
+        x = rnd(B * H * W, cin, seed=seed).half()
+        w = rnd(cout, cin, 3, 3, scale=1 / math.sqrt(9 * cin), seed=10 + seed)
+        wp, n_pad = ctx.pack_weight(w)
+        y = torch.zeros(B * H * W, cout, device=DEV, dtype=torch.float16)
+        sws = torch.zeros(ctx.gn_stats_floats(B, n_pad), device=DEV)
+        d = L.ConvDesc()
+        d.x1 = x.data_ptr(); d.c1 = cin; d.ld1 = cin; d.batch = B; d.in_h = H; d.in_w = W; d.ksize = 3; d.stride = 1
+        d.w_packed = wp.data_ptr(); d.n_out = cout; d.n_pad = n_pad; d.y = y.data_ptr(); d.ldy = cout
+        d.gn_stats_ws = sws.data_ptr(); d.gn_groups = 32
+        ctx.conv_override(-1, 1)
+        mode, nblk = ctx.conv_gn_fused(d)
+        ctx.conv(d)
+        ctx.conv_override(-1, 0)
+        assert mode == 2
+        outs.append(y); descs.append((sws, nblk, n_pad)); bufs.append((x, wp, d))
+    torch.cuda.synchronize()
+    h, sk = outs
+    C = h.shape[1] + sk.shape[1]
+    gamma, beta = 1 + 0.1 * rnd(C, seed=5), 0.1 * rnd(C, seed=6)
+    full, app = torch.zeros(B * H * W, C, device=DEV, dtype=torch.float16), torch.zeros(B * H * W, C, device=DEV, dtype=torch.float16)
+    ws = torch.zeros(ctx.groupnorm_ws_bytes(B, H * W) // 4, device=DEV)
+    ctx.groupnorm(h, h.shape[1], h.shape[1], sk, sk.shape[1], sk.shape[1], B, H * W, 32, gamma, beta, 1e-5, True, full, C, ws)
+    ctx._chk(ctx.lib.upk_groupnorm_apply_nhwc_f16(
+        ctx.h, h.data_ptr(), h.shape[1], h.shape[1], sk.data_ptr(), sk.shape[1], sk.shape[1], B, H * W, 32,
+        gamma.data_ptr(), beta.data_ptr(), 1e-5, 1, app.data_ptr(), C, descs[0][0].data_ptr(), 2, descs[0][1], descs[0][2],
+        descs[1][0].data_ptr(), descs[1][1], descs[1][2], ctx._s()))
+    torch.cuda.synchronize()
+    assert (app.float() - full.float()).abs().max().item() <= 2e-3 * full.float().abs().max().item()
+    x = torch.cat([h, sk], 1).float().view(B, H * W, C)
+    ref = F.silu(F.group_norm(x.permute(0, 2, 1), 32, gamma, beta, 1e-5)).permute(0, 2, 1)
+    check(app.view(B, H * W, C), ref, tol=1e-2)
+    with pytest.raises(L.UpkError):  # per-group partials cannot describe a concat
+        ctx._chk(ctx.lib.upk_groupnorm_apply_nhwc_f16(
+            ctx.h, h.data_ptr(), h.shape[1], h.shape[1], sk.data_ptr(), sk.shape[1], sk.shape[1], B, H * W, 32,
+            gamma.data_ptr(), beta.data_ptr(), 1e-5, 1, app.data_ptr(), C, descs[0][0].data_ptr(), 1, 0, descs[0][2],
+            None, 0, 0, ctx._s()))
 
 
 def test_qkv_gemm_with_transposed_v(ctx):

@@ -103,7 +103,7 @@ def load_library(path=None):
             "upk_groupnorm_nhwc_f16": (C.c_int, [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp,
                                                  f32, i32, vp, i32, vp, vp]),
             "upk_groupnorm_apply_nhwc_f16": (C.c_int, [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp,
-                                                       f32, i32, vp, i32, vp, i32, i32, i32, vp]),
+                                                       f32, i32, vp, i32, vp, i32, i32, i32, vp, i32, i32, vp]),
             "upk_conv_gn_fused": (C.c_int, [vp, C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
             "upk_groupnorm_ws_bytes": (C.c_size_t, [i32, i32]),
             "upk_layernorm_f16": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, f32, vp, i32, vp]),

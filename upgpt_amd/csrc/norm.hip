@@ -39,6 +39,8 @@ struct GnArgs {
   float* ws;  // [B][nchunks][groups][2]
   // apply pass fed by a conv epilogue's per-(row block, channel) partials: ws = [B][cp_nblk][2][cp_ld]
   int cp_nblk, cp_ld;
+  const float* ws2;  // channel partials of the second source (its own producer, its own blocking)
+  int cp_nblk2, cp_ld2;
 };
 
 __device__ __forceinline__ f16x8 gn_load(const GnArgs& a, long pix, int v) {
@@ -136,14 +138,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a, int rows_
     // per-(row block, channel) partials left by the producer conv's epilogue: fold the blocks per channel
     // (threads walk channels: coalesced), then the channels of each group, both in a fixed order
     float* chs = tab;  // [2][C] channel sums; overwritten by the scale / shift tables afterwards
-    const float* w = a.ws + (long)b * a.cp_nblk * 2 * a.cp_ld;
+    const float* w1 = a.ws + (long)b * a.cp_nblk * 2 * a.cp_ld;
+    const float* w2 = a.ws2 ? a.ws2 + (long)b * a.cp_nblk2 * 2 * a.cp_ld2 : nullptr;
     for (int idx = tid; idx < 2 * C; idx += 256) {
       const int which = idx >= C ? 1 : 0;
       const int ch = idx - which * C;
-      const float* src = w + which * a.cp_ld + ch;
+      const bool second = ch >= a.c1;  // channel of the second source of the concat
+      const int ld = second ? a.cp_ld2 : a.cp_ld;
+      const int nblk = second ? a.cp_nblk2 : a.cp_nblk;
+      const float* src = (second ? w2 + (ch - a.c1) : w1 + ch) + which * ld;
       float acc = 0.f;
 #pragma unroll 8
-      for (int k = 0; k < a.cp_nblk; ++k) acc += src[(long)k * 2 * a.cp_ld];
+      for (int k = 0; k < nblk; ++k) acc += src[(long)k * 2 * ld];
       chs[idx] = acc;
     }
     __syncthreads();
@@ -303,7 +309,8 @@ extern "C" size_t upk_groupnorm_ws_bytes(int batch, int hw) {
 
 static int gn_launch(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* x2, int c2, int ld2, int batch, int hw,
                      int groups, const float* gamma, const float* beta, float eps, int fuse_silu, void* y, int ldy,
-                     float* stats_ws, upk_stream stream_, bool with_stats, int cp_nblk = 0, int cp_ld = 0) {
+                     float* stats_ws, upk_stream stream_, bool with_stats, int cp_nblk = 0, int cp_ld = 0,
+                     const float* stats_ws2 = nullptr, int cp_nblk2 = 0, int cp_ld2 = 0) {
   if (!ctx) return UPK_EINVAL;
   if (!x1 || !gamma || !beta || !y || !stats_ws) return upk_fail(ctx, UPK_EINVAL, "groupnorm: null pointer");
   const int C = c1 + c2;
@@ -333,9 +340,13 @@ static int gn_launch(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* 
   a.ws = stats_ws;
   a.cp_nblk = cp_nblk;
   a.cp_ld = cp_ld;
-  if (cp_nblk > 0 && (c2 != 0 || cp_ld < C || cp_nblk > GN_MAX_CHUNKS))
-    return upk_fail(ctx, UPK_EINVAL, "groupnorm apply: channel partials need a single source, stats_ld >= C, nblk <= %d",
-                    GN_MAX_CHUNKS);
+  a.ws2 = stats_ws2;
+  a.cp_nblk2 = cp_nblk2;
+  a.cp_ld2 = cp_ld2;
+  if (cp_nblk > 0 && (cp_ld < c1 || cp_nblk > GN_MAX_CHUNKS ||
+                      (c2 != 0 && (!stats_ws2 || cp_ld2 < c2 || cp_nblk2 <= 0 || cp_nblk2 > GN_MAX_CHUNKS))))
+    return upk_fail(ctx, UPK_EINVAL, "groupnorm apply: channel partials need stats_ld >= channels and 0 < nblk <= %d for "
+                    "every source", GN_MAX_CHUNKS);
   upk_prof_scope prof(ctx, UPK_CLS_GN, stream);
   int rc = UPK_OK;
   if (with_stats) {
@@ -364,11 +375,15 @@ extern "C" int upk_groupnorm_apply_nhwc_f16(upk_ctx* ctx, const void* x1, int c1
                                             int ld2, int batch, int hw, int groups, const float* gamma,
                                             const float* beta, float eps, int fuse_silu, void* y, int ldy,
                                             const float* stats_ws, int stats_mode, int stats_nblk, int stats_ld,
+                                            const float* stats_ws2, int stats_nblk2, int stats_ld2,
                                             upk_stream stream) {
   if (stats_mode != 1 && stats_mode != 2) return upk_fail(ctx, UPK_EINVAL, "groupnorm apply: stats_mode %d", stats_mode);
   if (stats_mode == 2 && stats_nblk <= 0) return upk_fail(ctx, UPK_EINVAL, "groupnorm apply: stats_nblk %d", stats_nblk);
+  if (stats_mode == 1 && c2 != 0)
+    return upk_fail(ctx, UPK_EINVAL, "groupnorm apply: per-group partials (mode 1) describe a single-source tensor");
   return gn_launch(ctx, x1, c1, ld1, x2, c2, ld2, batch, hw, groups, gamma, beta, eps, fuse_silu, y, ldy,
-                   (float*)stats_ws, stream, false, stats_mode == 2 ? stats_nblk : 0, stats_ld);
+                   (float*)stats_ws, stream, false, stats_mode == 2 ? stats_nblk : 0, stats_ld, stats_ws2, stats_nblk2,
+                   stats_ld2);
 }
 
 extern "C" int upk_layernorm_f16(upk_ctx* ctx, const void* x, int ldx, int rows, int d, const float* gamma,

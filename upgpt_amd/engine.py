@@ -355,31 +355,53 @@ class Emitter:
         a = (x1.t.data_ptr(), x1.C, x1.ld, x2.t.data_ptr() if x2 is not None else None, x2.C if x2 is not None else 0,
              x2.ld if x2 is not None else 0, x1.B, x1.H * x1.W, 32, gamma.data_ptr(), beta.data_ptr(), float(eps),
              int(bool(silu)), y.t.data_ptr(), y.ld)
-        src = getattr(x1, "gn_src", None) if x2 is None else None
-        if src is None:
+        srcs = [getattr(x1, "gn_src", None)] + ([getattr(x2, "gn_src", None)] if x2 is not None else [])
+        if x2 is not None and os.environ.get("UPGPT_GN_2SRC", "1") != "1":
+            srcs = [None]
+        if x2 is not None and all(sr is not None for sr in srcs):
+            # a concat input is only worth arming when both producers are known to run unsplit (channel partials):
+            # a split-K producer's per-group partials cannot be combined across the seam
+            for sr in srcs:
+                key = self.convs[sr[1]][1]
+                e = TUNE_CACHE.get(key) or TUNE_CACHE.get(key[:-3] if key.endswith("_gs") else key + "_gs")
+                if e is None or e[1] != 1:
+                    srcs = [None]
+                    break
+        if any(sr is None for sr in srcs):
             P.add(lambda s: chk(fn(h, *a, ws.data_ptr(), s)), x1, x2, gamma, beta, y, ws, cls="groupnorm")
         else:
-            # the producer conv may have left the partial statistics of x1 in its own buffer (split-K launches
-            # only; decided by the tuned / cost-model split factor at the time the program runs or is captured)
-            d, ci = src
-            if not d.gn_stats_ws:  # arm the producer and rename its tuning key
-                sws = self.alloc(self.ctx.gn_stats_floats(x1.B, d.n_pad), dtype=torch.float32)
-                d.gn_stats_ws, d.gn_groups = sws.data_ptr(), 32
-                assert self.convs[ci][0] is d
-                self.convs[ci] = (d, self.convs[ci][1] + "_gs")
-                x1.gn_src = (d, ci, sws)
-            sws = x1.gn_src[2]
-            fused_fn, apply_fn, dref = self.lib.upk_conv_gn_fused, self.lib.upk_groupnorm_apply_nhwc_f16, C.byref(d)
+            # the producer conv(s) may have left the partial statistics of the input in their own buffers: per-group
+            # partials from a split-K reduce pass (single source only) or per-(M tile, channel) partials from an
+            # unsplit epilogue (every source of a concat must have them); decided by the tuned / cost-model choice
+            # at the time the program runs or is captured
+            armed = []
+            for act in ([x1] if x2 is None else [x1, x2]):
+                d = act.gn_src[0]
+                if not d.gn_stats_ws:  # arm the producer and rename its tuning key
+                    ci = act.gn_src[1]
+                    sws = self.alloc(self.ctx.gn_stats_floats(act.B, d.n_pad), dtype=torch.float32)
+                    d.gn_stats_ws, d.gn_groups = sws.data_ptr(), 32
+                    assert self.convs[ci][0] is d
+                    self.convs[ci] = (d, self.convs[ci][1] + "_gs")
+                    act.gn_src = (d, ci, sws)
+                armed.append((d, act.gn_src[2]))
+            fused_fn, apply_fn = self.lib.upk_conv_gn_fused, self.lib.upk_groupnorm_apply_nhwc_f16
 
             def run(s):
-                mode, nblk = C.c_int(0), C.c_int(0)
-                chk(fused_fn(h, dref, C.byref(mode), C.byref(nblk)))
-                if mode.value:
-                    chk(apply_fn(h, *a, sws.data_ptr(), mode.value, nblk.value, d.n_pad, s))
+                info = []
+                for d, sws in armed:
+                    mode, nblk = C.c_int(0), C.c_int(0)
+                    chk(fused_fn(h, C.byref(d), C.byref(mode), C.byref(nblk)))
+                    info.append((mode.value, nblk.value, d.n_pad, sws.data_ptr()))
+                if len(info) == 1 and info[0][0]:
+                    m, nb, ld, p1 = info[0]
+                    chk(apply_fn(h, *a, p1, m, nb, ld, None, 0, 0, s))
+                elif len(info) == 2 and info[0][0] == 2 and info[1][0] == 2:
+                    chk(apply_fn(h, *a, info[0][3], 2, info[0][1], info[0][2], info[1][3], info[1][1], info[1][2], s))
                 else:
                     chk(fn(h, *a, ws.data_ptr(), s))
 
-            P.add(run, x1, gamma, beta, y, ws, sws, d, cls="groupnorm")
+            P.add(run, x1, x2, gamma, beta, y, ws, armed, cls="groupnorm")
         P.n_launch += 1  # stats + apply
         return y
 
