@@ -14,7 +14,13 @@
  *   - every launcher enqueues on the given hipStream_t, never synchronises,
  *     never allocates (workspace is caller-provided through upk_set_workspace),
  *     is safe to capture in a HIP graph, and returns 0 or a negative UPK_E*;
- *   - no global mutable state outside upk_ctx.
+ *   - no global mutable state outside upk_ctx.  A context is NOT thread-safe:
+ *     one host thread per context at a time (one context per GPU process is
+ *     the intended use); different contexts are independent;
+ *   - the only entry points that synchronise or allocate are the offline
+ *     tools: upk_conv_autotune (times launches; with UPK_TUNE_COLD it keeps a
+ *     512 MB cache-flush buffer in the context until upk_destroy) and the
+ *     upk_prof_* collectors.
  *
  * Activation layout: NHWC / token-major fp16 ([B, H*W, C] == [M, C] row major,
  * leading dimension given in elements).  NCHW fp32 only at the public boundary

@@ -44,6 +44,7 @@ struct upk_ctx {
   void* zero_page;  // >= 256 B of zeros in HBM (padding source for direct-to-LDS loads)
   int cfg_override;
   int splitk_override;
+  void* tune_flush;  // 512 MB cache-flush buffer of the cold autotuner (allocated on first use)
   // profiling
   int prof_on;
   std::vector<upk_prof_rec> recs;       // recorded, not yet collected

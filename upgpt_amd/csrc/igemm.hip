@@ -1538,21 +1538,24 @@ extern "C" int upk_conv_autotune(upk_ctx* ctx, const upk_conv_desc* d, upk_strea
   if (ctx->prof_on) return upk_fail(ctx, UPK_EINVAL, "autotune with profiling enabled");
   hipStream_t stream = (hipStream_t)stream_;
   if (reps < 1) reps = 1;
+  // UPK_TUNE_COLD=1: every timed launch runs behind a 512 MB memset, i.e. with the L2s and the
+  // Infinity Cache flushed — inside the UNet forward a launch never finds its weights (850 MB cycle
+  // through per forward) or its freshly produced activations in the local L2, which back-to-back
+  // launches of one shape do.  The flush buffer belongs to the context (freed by upk_destroy).
+  static const bool cold = getenv("UPK_TUNE_COLD") != nullptr;
+  const size_t flush_bytes = (size_t)512 << 20;
+  if (cold && !ctx->tune_flush) UPK_HIP(ctx, hipMalloc(&ctx->tune_flush, flush_bytes));
+  void* const flush_buf = ctx->tune_flush;
   hipEvent_t e0, e1;
   UPK_HIP(ctx, hipEventCreate(&e0));
-  UPK_HIP(ctx, hipEventCreate(&e1));
+  if (hipEventCreate(&e1) != hipSuccess) {
+    (void)hipEventDestroy(e0);
+    return upk_fail(ctx, UPK_EHIP, "autotune: hipEventCreate failed");
+  }
   const int save_cfg = ctx->cfg_override, save_sk = ctx->splitk_override;
   upk_conv_desc dd = *d;
   dd.tune_cfg = 0;
   dd.tune_splitk = 0;
-  // UPK_TUNE_COLD=1: every timed launch runs behind a 512 MB memset, i.e. with the L2s and the
-  // Infinity Cache flushed — inside the UNet forward a launch never finds its weights (850 MB cycle
-  // through per forward) or its freshly produced activations in the local L2, which back-to-back
-  // launches of one shape do.
-  static const bool cold = getenv("UPK_TUNE_COLD") != nullptr;
-  static void* flush_buf = nullptr;
-  const size_t flush_bytes = (size_t)512 << 20;
-  if (cold && !flush_buf) UPK_HIP(ctx, hipMalloc(&flush_buf, flush_bytes));
   auto time_one = [&](int cfg, int sk, float* us) -> int {
     ctx->cfg_override = cfg;
     ctx->splitk_override = sk;

@@ -22,6 +22,7 @@ extern "C" int upk_create(upk_ctx** out, int device) {
   c->ws = nullptr;
   c->ws_bytes = 0;
   c->zero_page = nullptr;
+  c->tune_flush = nullptr;
   {
     int cur = 0;
     (void)hipGetDevice(&cur);
@@ -54,6 +55,7 @@ extern "C" int upk_destroy(upk_ctx* ctx) {
     (void)hipEventDestroy(r.e1);
   }
   if (ctx->zero_page) (void)hipFree(ctx->zero_page);
+  if (ctx->tune_flush) (void)hipFree(ctx->tune_flush);
   delete ctx;
   return UPK_OK;
 }
