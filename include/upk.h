@@ -207,6 +207,12 @@ int upk_attention_causal_f16(upk_ctx* ctx, const void* q, int ldq, long long q_b
 int upk_embed_tokens_f16(upk_ctx* ctx, const int32_t* ids, const void* tok_emb, const void* pos_emb, int rows,
                          int seq, int dim, int vocab, void* out, int ld_out, upk_stream stream);
 
+/* y[i, :] = x[idx[i], :] for i < n (fp16 rows of `dim` channels, idx = device int32[n], clamped to [0, n_src)):
+ * the end-of-text pooling of `clip.model.CLIP.encode_text` (x[arange, text.argmax(-1)]) behind
+ * FrozenCLIPTextEmbedder (ldm/modules/encoders/modules.py:164-198); the argmax over the token ids is host logic. */
+int upk_gather_rows_f16(upk_ctx* ctx, const void* x, int ldx, const int32_t* idx, int n, int n_src, int dim,
+                        void* y, int ldy, upk_stream stream);
+
 /* CLIP image tower (ldm/modules/encoders/modules.py:234-256 -> clip.model.VisionTransformer):
  * patch embedding = upk_patchify_nchw_f32_f16 (non-overlapping p x p patches of an fp32 NCHW image -> fp16 rows
  * [batch*(H/p)*(W/p), ld_out], k = c*p*p + py*p + px, zero padded) followed by a plain upk_gemm_f16 with the

@@ -4,19 +4,8 @@
   available offline, so `encode(text)` needs them on disk and `encode_tokens(ids)` takes token ids.
 * FrozenClipImageEmbedder2 (modules.py:234-256): CLIP ViT-L/14 image tower (upgpt_amd/clip_image.py),
   [b, n, 3, 224, 224] pre-processed crops -> [b, n, 768].
-* FrozenCLIPTextEmbedder (the `clip`-package text encoder, unused by the UPGPT configs) is not built."""
-from torch import nn
-
+* FrozenCLIPTextEmbedder (modules.py:164-198): the `clip`-package text encoder InferenceModel.mix_style uses
+  (upgpt_amd/clip_text.py, OpenAI key layout, end-of-text pooling + text_projection -> [n, 768])."""
 from upgpt_amd.clip_image import CLIPVisual, FrozenClipImageEmbedder2  # noqa: F401
-from upgpt_amd.clip_text import CLIPTextTransformer, FrozenCLIPEmbedder  # noqa: F401
-
-
-class FrozenCLIPTextEmbedder(nn.Module):
-    def __init__(self, *args, **kwargs):
-        super().__init__()
-
-    def forward(self, *a, **k):
-        raise NotImplementedError("FrozenCLIPTextEmbedder (clip-package text encoder) is not used by the UPGPT configs and "
-                                  "is not part of upgpt_amd; FrozenCLIPEmbedder is")
-
-    encode = forward
+from upgpt_amd.clip_text import (CLIPTextTower, CLIPTextTransformer, FrozenCLIPEmbedder,  # noqa: F401
+                                 FrozenCLIPTextEmbedder)

@@ -102,6 +102,48 @@ def test_clip_text_tower_vs_transformers_golden():
         enc.encode_tokens(torch.full((2, 77), 49408))
 
 
+def test_gather_rows(ctx):
+    x = rnd(50, 96, seed=3).half()[:, :64]       # leading dimension 96, 64 channels used
+    idx = torch.tensor([7, 0, 49, 7, 200, -3], dtype=torch.int32, device=DEV)  # out-of-range rows clamp
+    y = torch.full((6, 72), float("nan"), device=DEV, dtype=torch.float16)
+    ctx.gather_rows(x, 96, idx, 6, 50, 64, y, 72)
+    torch.cuda.synchronize()
+    assert torch.equal(y[:, :64], x[[7, 0, 49, 7, 49, 0]]) and torch.isnan(y[:, 64:]).all()
+    with pytest.raises(RuntimeError):
+        ctx.gather_rows(x, 96, idx, 6, 50, 60, y, 72)  # dim not a multiple of 8
+
+
+def test_clip_text_embedder_vs_transformers_golden():
+    """FrozenCLIPTextEmbedder (modules.py:164-198; clip-package encode_text: end-of-text pooling + text_projection)."""
+    from ldm.modules.encoders.modules import FrozenCLIPTextEmbedder
+    g = np.load(os.path.join(G, "clip_textproj.npz"))
+    enc = FrozenCLIPTextEmbedder(normalize=False)
+    sd = {k: synth.synth_tensor("clip_text_encoder." + k, tuple(v.shape)) for k, v in enc.state_dict().items()}
+    assert len(sd) == int(g["n_keys"]) and "model.transformer.resblocks.11.attn.in_proj_weight" in sd
+    enc.load_state_dict(sd)
+    enc = enc.cuda()
+    ids = torch.as_tensor(g["ids"]).long()
+    z = enc.encode_tokens(ids)
+    ref = torch.as_tensor(g["text_embeds"])
+    assert z.shape == (9, 768) and torch.isfinite(z).all()
+    err = (z.cpu() - ref).abs()
+    rel = float(err.max()) / float(ref.abs().max())
+    print("CLIP text embedder vs transformers golden: mse %.3e, max err %.3e (|ref| mean %.3f, max rel %.3e)" % (
+        float((err ** 2).mean()), float(err.max()), float(g["abs_mean"]), rel))
+    assert float((err ** 2).mean()) < 1e-4 and rel < 2e-2
+    # the reference's call shapes: forward([list of strings]) -> [1, n, 768] through the tokenizer hook; normalize=True
+    enc.tokenizer = lambda texts: ids[:len(texts)]
+    z3 = enc([["a", "b", "c"]])
+    assert z3.shape == (1, 3, 768) and torch.equal(z3[0], enc.encode_tokens(ids[:3]))
+    enc.normalize = True
+    zn = enc.encode_tokens(ids)
+    assert torch.allclose(zn.norm(dim=1), torch.ones(9, device=zn.device), atol=1e-4)
+    assert torch.allclose(zn, z / z.norm(dim=1, keepdim=True), atol=1e-5)
+    enc.tokenizer = None
+    with pytest.raises(RuntimeError):
+        enc([["a photo"]])  # no `clip` package / vocabulary offline: a clear error, not a fallback
+
+
 def test_vit_patchify_and_assemble(ctx):
     N, C, H, W, p, dim = 2, 3, 28, 42, 14, 64
     x = rnd(N, C, H, W)

@@ -22,7 +22,7 @@ SYMBOLS = [
     "upk_layernorm_f16", "upk_timestep_embed_f16",
     "upk_nchw_f32_to_nhwc_f16", "upk_nhwc_f16_to_nchw_f32", "upk_f32_to_f16", "upk_ddim_step_f32",
     "upk_ddim_step_cfg_f32", "upk_plms_step_f32", "upk_attention_causal_f16", "upk_embed_tokens_f16",
-    "upk_patchify_nchw_f32_f16", "upk_vit_assemble_f16",
+    "upk_patchify_nchw_f32_f16", "upk_vit_assemble_f16", "upk_gather_rows_f16",
     "upk_advance_step", "upk_graph_begin", "upk_graph_end", "upk_graph_launch", "upk_graph_destroy",
     "upk_prof_enable", "upk_prof_collect",
 ]
@@ -98,6 +98,7 @@ def load_library(path=None):
             "upk_attention_causal_f16": (C.c_int, [vp, vp, i32, i64, vp, i32, i64, vp, i32, vp, i32, i64,
                                                    i32, i32, i32, i32, f32, vp]),
             "upk_embed_tokens_f16": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
+            "upk_gather_rows_f16": (C.c_int, [vp, vp, i32, vp, i32, i32, i32, vp, i32, vp]),
             "upk_patchify_nchw_f32_f16": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp, i32, vp]),
             "upk_vit_assemble_f16": (C.c_int, [vp, vp, i32, vp, vp, i32, i32, i32, vp, i32, vp]),
             "upk_groupnorm_nhwc_f16": (C.c_int, [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp,
@@ -209,6 +210,9 @@ class Context:
     def embed_tokens(self, ids, tok, pos, rows, seq, dim, vocab, out, ld):
         self._chk(self.lib.upk_embed_tokens_f16(self.h, _ptr(ids), _ptr(tok), _ptr(pos), rows, seq, dim, vocab, _ptr(out),
                                                 ld, self._s()))
+
+    def gather_rows(self, x, ldx, idx, n, n_src, dim, y, ldy):
+        self._chk(self.lib.upk_gather_rows_f16(self.h, _ptr(x), ldx, _ptr(idx), n, n_src, dim, _ptr(y), ldy, self._s()))
 
     def groupnorm(self, x1, c1, ld1, x2, c2, ld2, batch, hw, groups, gamma, beta, eps, silu, y, ldy, ws):
         self._chk(self.lib.upk_groupnorm_nhwc_f16(self.h, _ptr(x1), c1, ld1, _ptr(x2), c2, ld2, batch, hw, groups,

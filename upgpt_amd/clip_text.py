@@ -11,6 +11,11 @@ MLP 768 -> 3072 -> 768 with quick_gelu) -> final LayerNorm; the embedder returns
 * Compute: `upk_embed_tokens_f16`, LayerNorm folded into the fused q|k|v projection and into fc1
   (`upk_conv_desc.ln_colsum`), `upk_attention_causal_f16`, `UPK_F_QUICKGELU` epilogue, residual epilogues,
   `upk_layernorm_f16` for the final norm.  One program per batch size; no torch op computes anything.
+* `FrozenCLIPTextEmbedder` (modules.py:164-198) is the OTHER text encoder of the reference — OpenAI's `clip` package
+  model (`clip.model.CLIP.encode_text`: the same 12-layer tower under the package's own key names, then ln_final on
+  the end-of-text row and `@ text_projection` -> [n, 768]); `InferenceModel.mix_style` (ldm/data/generate_utils.py:
+  170-189) uses it to replace style-image embeddings by text.  Same program with the `OPENAI_NAMES` table plus
+  `upk_gather_rows_f16` + a projection GEMM.
 * `FrozenCLIPEmbedder` mirrors the reference class.  Its tokenizer (vocab / merges files of the hub model) is not
   available offline: `encode(text)` needs `transformers.CLIPTokenizer` files on disk, `encode_tokens(ids)` takes the
   int token ids directly (the oracle boundary for this stage).
@@ -48,12 +53,46 @@ def text_param_shapes(cfg):
     return s
 
 
+# weight names of the two layouts the tower is stored under
+HF_NAMES = dict(tok="text_model.embeddings.token_embedding.weight", pos="text_model.embeddings.position_embedding.weight",
+                layer="text_model.encoder.layers.%d.", qkv=["self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"],
+                ln1="layer_norm1", out="self_attn.out_proj", ln2="layer_norm2", fc1="mlp.fc1", fc2="mlp.fc2",
+                final="text_model.final_layer_norm", proj=None)
+OPENAI_NAMES = dict(tok="token_embedding.weight", pos="positional_embedding", layer="transformer.resblocks.%d.",
+                    qkv="attn.in_proj", ln1="ln_1", out="attn.out_proj", ln2="ln_2", fc1="mlp.c_fc", fc2="mlp.c_proj",
+                    final="ln_final", proj="text_projection")
+
+
+def openai_text_param_shapes(cfg):
+    """Text half of `clip.model.CLIP` (ViT-L/14: transformer_width 768, 12 layers, 12 heads, embed_dim 768)."""
+    d, f = cfg["hidden_size"], cfg["intermediate_size"]
+    s = {"token_embedding.weight": (cfg["vocab_size"], d), "positional_embedding": (cfg["max_position_embeddings"], d),
+         "ln_final.weight": (d,), "ln_final.bias": (d,), "text_projection": (d, cfg.get("projection_dim", d))}
+    for i in range(cfg["num_hidden_layers"]):
+        b = "transformer.resblocks.%d." % i
+        s[b + "attn.in_proj_weight"], s[b + "attn.in_proj_bias"] = (3 * d, d), (3 * d,)
+        s[b + "attn.out_proj.weight"], s[b + "attn.out_proj.bias"] = (d, d), (d,)
+        s[b + "ln_1.weight"], s[b + "ln_1.bias"] = (d,), (d,)
+        s[b + "mlp.c_fc.weight"], s[b + "mlp.c_fc.bias"] = (f, d), (f,)
+        s[b + "mlp.c_proj.weight"], s[b + "mlp.c_proj.bias"] = (d, f), (d,)
+        s[b + "ln_2.weight"], s[b + "ln_2.bias"] = (d,), (d,)
+    return s
+
+
 class _TextPlan(Emitter):
     """Launch program of the text tower for one batch size."""
 
-    def __init__(self, ctx, cfg, get, B):
+    def __init__(self, ctx, cfg, get, B, names=HF_NAMES):
         super().__init__(ctx)
-        self.cfg, self.B = cfg, B
+        self.cfg, self.B, self.pooled = cfg, B, names["proj"] is not None
+        nm, raw = names, get
+        if isinstance(nm["qkv"], str):  # OpenAI layout: packer-style "<name>.weight / .bias" on top of in_proj_weight
+            def get(n):
+                if n.endswith("in_proj.weight") or n.endswith("in_proj.bias"):
+                    return raw(n.replace("in_proj.", "in_proj_"))
+                if n == "proj_t.weight":
+                    return raw(nm["proj"]).t().contiguous()
+                return raw(n)
         d, f = cfg["hidden_size"], cfg["intermediate_size"]
         S, heads = cfg["max_position_embeddings"], cfg["num_attention_heads"]
         dh = d // heads
@@ -63,8 +102,8 @@ class _TextPlan(Emitter):
         pk = Packer(ctx, get)
         M = B * S
         self.ids = self.alloc(M, dtype=torch.int32)
-        self.tok = get("text_model.embeddings.token_embedding.weight").half().contiguous()
-        self.pos = get("text_model.embeddings.position_embedding.weight").half().contiguous()
+        self.tok = get(nm["tok"]).half().contiguous()
+        self.pos = get(nm["pos"]).half().contiguous()
         x = Act(self.alloc(M, d), B, S, 1, d)
         P = self.prog = Program(ctx)
         fn_e, h, chk = self.lib.upk_embed_tokens_f16, self.hctx, self._chk
@@ -73,10 +112,10 @@ class _TextPlan(Emitter):
         vt_ld = _rup(S, 32)
         fn_a = self.lib.upk_attention_causal_f16
         for i in range(cfg["num_hidden_layers"]):
-            p = "text_model.encoder.layers.%d." % i
-            # layer_norm1 folded into the fused q|k|v projection; V leaves the GEMM transposed for the attention kernel
-            wqkv = pk.pack([p + "self_attn.q_proj", p + "self_attn.k_proj", p + "self_attn.v_proj"], n_out=2 * d,
-                           ln=p + "layer_norm1")
+            p = nm["layer"] % i
+            # first LayerNorm folded into the fused q|k|v projection; V leaves the GEMM transposed for the attention kernel
+            qkv = [p + q for q in nm["qkv"]] if isinstance(nm["qkv"], list) else p + nm["qkv"]
+            wqkv = pk.pack(qkv, n_out=2 * d, ln=p + nm["ln1"])
             qk = Act(self.alloc(M, 2 * d), B, S, 1, 2 * d)
             vt = self.alloc(B, heads, dh, vt_ld, zero=True)
             self.conv(P, x, wqkv, out=qk, ln_eps=eps,
@@ -85,15 +124,29 @@ class _TextPlan(Emitter):
             aa = (qk.t.data_ptr(), 2 * d, S * 2 * d, qk.t[:, d:].data_ptr(), 2 * d, S * 2 * d, vt.data_ptr(), vt_ld,
                   att.t.data_ptr(), d, S * d, B, heads, S, dh, float(dh ** -0.5))
             P.add(lambda s, aa=aa: chk(fn_a(h, *aa, s)), qk, vt, att, cls="attention")
-            x = self.conv(P, att, pk.pack(p + "self_attn.out_proj"), residual=x)
-            # layer_norm2 folded into fc1; quick_gelu in its epilogue; fc2 adds the residual
-            hmid = self.conv(P, x, pk.pack(p + "mlp.fc1", ln=p + "layer_norm2"), ln_eps=eps, flags=L.F_QUICKGELU)
-            x = self.conv(P, hmid, pk.pack(p + "mlp.fc2"), residual=x)
-        self.out = Act(self.alloc(M, d), B, S, 1, d)
-        g, b_ = pk.vec("text_model.final_layer_norm.weight"), pk.vec("text_model.final_layer_norm.bias")
+            x = self.conv(P, att, pk.pack(p + nm["out"]), residual=x)
+            # second LayerNorm folded into the first MLP GEMM; quick_gelu in its epilogue; the second adds the residual
+            hmid = self.conv(P, x, pk.pack(p + nm["fc1"], ln=p + nm["ln2"]), ln_eps=eps, flags=L.F_QUICKGELU)
+            x = self.conv(P, hmid, pk.pack(p + nm["fc2"]), residual=x)
+        g, b_ = pk.vec(nm["final"] + ".weight"), pk.vec(nm["final"] + ".bias")
         fn_l = self.lib.upk_layernorm_f16
-        al = (x.t.data_ptr(), x.ld, M, d, g.data_ptr(), b_.data_ptr(), eps, self.out.t.data_ptr(), self.out.ld)
-        P.add(lambda s: chk(fn_l(h, *al, s)), x, g, b_, self.out, cls="layernorm")
+        if self.pooled:
+            # clip.model.CLIP.encode_text: ln_final, the end-of-text row of each sequence, @ text_projection
+            # (LayerNorm is per row, so the rows are gathered first)
+            self.eot = self.alloc(B, dtype=torch.int32)
+            rows = Act(self.alloc(B, d), B, 1, 1, d)
+            fn_g = self.lib.upk_gather_rows_f16
+            ag = (x.t.data_ptr(), x.ld, self.eot.data_ptr(), B, M, d, rows.t.data_ptr(), rows.ld)
+            P.add(lambda s: chk(fn_g(h, *ag, s)), x, self.eot, rows, cls="other")
+            normed = Act(self.alloc(B, d), B, 1, 1, d)
+            al = (rows.t.data_ptr(), rows.ld, B, d, g.data_ptr(), b_.data_ptr(), eps, normed.t.data_ptr(), normed.ld)
+            P.add(lambda s: chk(fn_l(h, *al, s)), rows, g, b_, normed, cls="layernorm")
+            self.out_f32 = self.alloc(B, get("proj_t.weight").shape[0], dtype=torch.float32)
+            self.conv(P, normed, pk.pack("proj_t", bias=False), out_f32=self.out_f32)
+        else:
+            self.out = Act(self.alloc(M, d), B, S, 1, d)
+            al = (x.t.data_ptr(), x.ld, M, d, g.data_ptr(), b_.data_ptr(), eps, self.out.t.data_ptr(), self.out.ld)
+            P.add(lambda s: chk(fn_l(h, *al, s)), x, g, b_, self.out, cls="layernorm")
         self.apply_tuning(tune_missing=os.environ.get("UPGPT_AUTOTUNE", "0") == "1")
 
     def run(self, ids):
@@ -103,30 +156,33 @@ class _TextPlan(Emitter):
         if int(ids.min()) < 0 or int(ids.max()) >= self.cfg["vocab_size"]:
             raise ValueError("token id outside [0, %d)" % self.cfg["vocab_size"])
         self.ids.copy_(ids.reshape(-1).to(self.dev, torch.int32))
+        if self.pooled:
+            # end-of-text = the highest token id of each sequence (clip/model.py encode_text: text.argmax(dim=-1))
+            S = self.cfg["max_position_embeddings"]
+            eot = ids.argmax(dim=-1).to(torch.int64).cpu() + torch.arange(self.B, dtype=torch.int64) * S
+            self.eot.copy_(eot.to(torch.int32))
+            self.prog.run()
+            return self.out_f32.clone()
         self.prog.run()
         return self.out.t.float().view(self.B, self.cfg["max_position_embeddings"], -1)
 
 
-class CLIPTextTransformer(ParamTree):
-    """Weights + forward of the CLIP text tower; `forward(input_ids)` returns an object with `.last_hidden_state`
-    like transformers' CLIPTextModel (that is all the reference reads, modules.py:156-158)."""
+class _TextTower(ParamTree):
+    """Weights of one storage layout + the per-batch-size launch programs."""
+    NAMES = HF_NAMES
 
-    def __init__(self, **config):
+    def __init__(self, shapes, config):
         super().__init__()
-        self.config = dict(CLIP_L14_TEXT, **config)
-        self.add_params(text_param_shapes(self.config))
+        self.config = config
+        self.add_params(shapes)
         self._plans = {}
         self._fp = None
 
-    class Output:
-        def __init__(self, last_hidden_state):
-            self.last_hidden_state = last_hidden_state
-
-    def forward(self, input_ids):
+    def _run(self, input_ids):
         p = next(self.parameters())
         if p.device.type != "cuda":
-            raise RuntimeError("upgpt_amd.CLIPTextTransformer computes only through the HIP kernels on an MI355X: move it "
-                               "to 'cuda' first. There is no CPU fallback.")
+            raise RuntimeError("upgpt_amd.%s computes only through the HIP kernels on an MI355X: move it to 'cuda' first. "
+                               "There is no CPU fallback." % type(self).__name__)
         from ._lib import get_context
         fp = weights_fingerprint(self)
         if fp != self._fp:
@@ -138,9 +194,41 @@ class CLIPTextTransformer(ParamTree):
                 self._plans.pop(next(iter(self._plans)))
             params = dict(self.named_parameters())
             with torch.cuda.device(p.device):
-                plan = self._plans[B] = _TextPlan(get_context(p.device), self.config, lambda n: params[n].data, B)
+                plan = self._plans[B] = _TextPlan(get_context(p.device), self.config, lambda n: params[n].data, B,
+                                                  names=self.NAMES)
         with torch.cuda.device(p.device):
-            return CLIPTextTransformer.Output(plan.run(input_ids))
+            return plan.run(input_ids)
+
+
+class CLIPTextTransformer(_TextTower):
+    """Weights + forward of the CLIP text tower; `forward(input_ids)` returns an object with `.last_hidden_state`
+    like transformers' CLIPTextModel (that is all the reference reads, modules.py:156-158)."""
+
+    def __init__(self, **config):
+        cfg = dict(CLIP_L14_TEXT, **config)
+        super().__init__(text_param_shapes(cfg), cfg)
+
+    class Output:
+        def __init__(self, last_hidden_state):
+            self.last_hidden_state = last_hidden_state
+
+    def forward(self, input_ids):
+        return CLIPTextTransformer.Output(self._run(input_ids))
+
+
+class CLIPTextTower(_TextTower):
+    """Text half of OpenAI's `clip.model.CLIP` under the package's key names; `encode_text(tokens)` -> [n, 768]
+    (clip/model.py CLIP.encode_text; the image half lives in upgpt_amd/clip_image.py)."""
+    NAMES = OPENAI_NAMES
+
+    def __init__(self, **config):
+        cfg = dict(CLIP_L14_TEXT, **config)
+        super().__init__(openai_text_param_shapes(cfg), cfg)
+
+    def encode_text(self, tokens):
+        return self._run(tokens)
+
+    forward = encode_text
 
 
 class FrozenCLIPEmbedder(nn.Module):
@@ -185,3 +273,58 @@ class FrozenCLIPEmbedder(nn.Module):
 
     def encode(self, text):
         return self(text)
+
+
+class FrozenCLIPTextEmbedder(nn.Module):
+    """Drop-in for ldm.modules.encoders.modules.FrozenCLIPTextEmbedder (modules.py:164-198): `model` is the text half of
+    the `clip` package's CLIP (state-dict keys `model.token_embedding.weight`, `model.transformer.resblocks.N...`,
+    `model.ln_final.*`, `model.text_projection` as `clip.load` produces them).  `forward(texts)`: `texts` is a list whose
+    items are each a string or a list of strings; every item yields [n, 768] and the results are stacked.
+
+    `clip.tokenize` needs the package's BPE vocabulary, which is not available offline: pass `tokenizer=` (a callable
+    strings -> int tensor [n, 77]) or call `encode_tokens(ids)`.  The optional L2 normalisation of the [n, 768] result is
+    host-side post-processing (one torch expression on a few KB)."""
+
+    def __init__(self, version="ViT-L/14", device="cuda", max_length=77, n_repeat=1, normalize=True, tokenizer=None,
+                 **config):
+        super().__init__()
+        if version != "ViT-L/14" and not config:
+            raise NotImplementedError("only the ViT-L/14 text tower of the reference is described here; pass the tower "
+                                      "dimensions as keyword arguments for another one")
+        self.model = CLIPTextTower(max_position_embeddings=max_length, **config)
+        self.device, self.max_length, self.n_repeat, self.normalize = device, max_length, n_repeat, normalize
+        self.tokenizer = tokenizer
+        self.freeze()
+
+    def freeze(self):
+        self.model = self.model.eval()
+        for param in self.parameters():
+            param.requires_grad = False
+
+    def _tokenize(self, text):
+        if self.tokenizer is None:
+            try:
+                import clip  # the OpenAI package, if the user has it
+                self.tokenizer = clip.tokenize
+            except Exception as e:
+                raise RuntimeError("FrozenCLIPTextEmbedder needs the `clip` package's tokenizer (BPE vocabulary, not "
+                                   "available offline): pass tokenizer=..., or call encode_tokens(input_ids) with [n, %d] "
+                                   "token ids" % self.max_length) from e
+        return self.tokenizer(text)
+
+    @torch.no_grad()
+    def encode_tokens(self, tokens):
+        z = self.model.encode_text(tokens)
+        if self.normalize:
+            z = z / torch.linalg.norm(z, dim=1, keepdim=True)
+        return z
+
+    @torch.no_grad()
+    def forward(self, texts):
+        return torch.stack([self.encode_tokens(self._tokenize(text)) for text in texts])
+
+    def encode(self, text):
+        z = self(text)
+        if z.ndim == 2:
+            z = z[:, None, :].repeat(1, self.n_repeat, 1)
+        return z

@@ -328,6 +328,18 @@ __global__ void embed_tokens_kernel(const int* ids, const f16* tok, const f16* p
   *(f16x8*)(out + (long)r * ld + v * 8) = o;
 }
 
+// y[i, :] = x[idx[i], :]  (one thread per 8 channels)
+__global__ void gather_rows_kernel(const f16* x, int ldx, const int* idx, int n, int n_src, int dim, f16* y, int ldy) {
+  const int vpr = dim >> 3;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)n * vpr) return;
+  const int i = (int)(t / vpr);
+  const int v = (int)(t - (long)i * vpr);
+  int r = idx[i];
+  r = r < 0 ? 0 : (r >= n_src ? n_src - 1 : r);
+  *(f16x8*)(y + (long)i * ldy + v * 8) = *(const f16x8*)(x + (long)r * ldx + v * 8);
+}
+
 __global__ void advance_step_kernel(int* step) { *step += 1; }
 
 }  // namespace
@@ -453,6 +465,19 @@ extern "C" int upk_embed_tokens_f16(upk_ctx* ctx, const int32_t* ids, const void
   hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, ids,
                      (const f16*)tok_emb, (const f16*)pos_emb, rows, seq, dim, vocab, (f16*)out, ld_out);
   return upk_check_launch(ctx, "embed_tokens");
+}
+
+extern "C" int upk_gather_rows_f16(upk_ctx* ctx, const void* x, int ldx, const int32_t* idx, int n, int n_src, int dim,
+                                   void* y, int ldy, upk_stream stream_) {
+  if (!ctx) return UPK_EINVAL;
+  if (!x || !idx || !y || n <= 0 || n_src <= 0 || dim <= 0 || (dim & 7) || ldx < dim || (ldx & 7) || ldy < dim ||
+      (ldy & 7))
+    return upk_fail(ctx, UPK_EINVAL, "gather_rows: bad args (dim, ldx and ldy must be multiples of 8)");
+  const long t = (long)n * (dim >> 3);
+  upk_prof_scope prof(ctx, UPK_CLS_OTHER, (hipStream_t)stream_);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
+                     (const f16*)x, ldx, idx, n, n_src, dim, (f16*)y, ldy);
+  return upk_check_launch(ctx, "gather_rows");
 }
 
 extern "C" int upk_advance_step(upk_ctx* ctx, int32_t* step, upk_stream stream_) {
