@@ -21,10 +21,10 @@ upgpt_amd/clip_{text,image}.py) live in third-party packages the reference does 
 vendor: transformers' CLIPTextModel (4.19.2 pinned by its environment.yaml) and OpenAI's
 `clip` package.  There is no restatement of them here: the checker for those stages is
 the transformers implementation itself, run on CPU fp32 by
-tests/golden/make_clip_{text,image}_golden.py in the build container (transformers
+tests/golden/make_clip_{text,image,textproj}_golden.py in the build container (transformers
 5.15.0; CLIPVisionModelWithProjection is the same VisionTransformer as the clip
 package's), with recipe weights and seeded inputs; only ids / seeds + outputs are
-committed (tests/golden/clip_{text,image}.npz).  Their tokenizer / crop pre-processing
+committed (tests/golden/clip_{text,image,textproj}.npz).  Their tokenizer / crop pre-processing
 and trained weights are not available offline: parity is pinned on the towers from
 token ids / pre-processed crops to embeddings.
 """
