@@ -148,6 +148,17 @@ typedef struct upk_conv_desc {
    * cost-model (tile, split-K) choice, the same decision procedure as the launch. */
   float* gn_stats_ws;
   int32_t gn_groups;
+  /* Appended 1x1 K segment — the ResBlock skip projection folded into its second conv
+   * (openaimodel.py:274-275: `skip_connection(x) + h` with skip_connection = conv1x1 when channels change):
+   *   y = conv_ksize(x1 | x2) + conv1x1(x3 | x4) + bias ...
+   * x3 (and optionally x4, concatenated along C like x1 | x2) are NHWC fp16 sources with the OUTPUT's spatial
+   * dims (stride 1, no upsample); c3, c4 multiples of 32.  The packed weight is the main weight followed by the
+   * 1x1 weight along K ((ksize^2 (c1+c2) + c3+c4) / 32 chunks of [n_pad][32]); bias = sum of both biases.
+   * Wave-specialised tile configurations only (the classic kernels refuse).  x3 == NULL: off. */
+  const void* x3;
+  const void* x4;
+  int32_t c3, c4;
+  int32_t ld3, ld4;
 } upk_conv_desc;
 
 /* Replaces F.conv2d (3x3 s1/s2 p1, 1x1) / F.linear call sites:

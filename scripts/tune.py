@@ -48,14 +48,22 @@ for kind in kinds:
     if kind == "bbox_cfg":  # classifier-free guidance runs the UNet on 2*B rows
         shapes, kind = [(16, 32, 32, 50), (16, 32, 24, 50)], "bbox"
     for (B, H, W, S) in shapes:
-        for fold in ("1", "0"):  # LayerNorm folded into its consumer GEMM / separate: both get measured
-            os.environ["UPGPT_LN_FOLD"] = fold
+        # LayerNorm folded into its consumer GEMM / separate, ResBlock skip projection appended to the second conv /
+        # separate: every variant gets measured, the emitter then picks per shape
+        for fold, skf in (("1", "0"), ("0", "0"), (None, "1")):
+            if fold is None:
+                os.environ.pop("UPGPT_LN_FOLD", None)
+            else:
+                os.environ["UPGPT_LN_FOLD"] = fold
+            os.environ["UPGPT_SKIP_FOLD"] = skf
             unet._plans.clear()
             t0 = time.time()
             pl = unet.plan(B, H, W, ntok, S, "sampler")
-            summarize("%s unet sampler B=%d %dx%d ln_fold=%s (%.0fs)" % (kind, B, H, W, fold, time.time() - t0), pl)
+            summarize("%s unet sampler B=%d %dx%d ln_fold=%s skip_fold=%s (%.0fs)" % (kind, B, H, W, fold, skf,
+                                                                                      time.time() - t0), pl)
             TUNE_CACHE.save(out)
-        os.environ.pop("UPGPT_LN_FOLD")
+        os.environ.pop("UPGPT_LN_FOLD", None)
+        os.environ.pop("UPGPT_SKIP_FOLD", None)
         unet._plans.clear()
         t0 = time.time()
         vp = model.first_stage_model._decode_plan(B, H, W, 0.18215)

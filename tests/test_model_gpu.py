@@ -65,6 +65,46 @@ def test_unet_forward_vs_reference_golden_and_oracle(kind):
         assert mse(got, ref) < 1e-4
 
 
+@pytest.mark.parametrize("kind", ["tiny", "bbox", "upscale"])
+def test_skip_projection_folded_into_second_conv_vs_reference_golden(kind, monkeypatch):
+    """UPGPT_SKIP_FOLD=1: every ResBlock whose channel count changes runs its 1x1 skip projection as an appended K
+    segment of its second conv (include/upk.h x3/x4) — same goldens, same tolerances; and the folded and the
+    two-launch programs agree to fp16 rounding (the fold drops the fp16 round trip of the skip tensor)."""
+    model, _ = get_model(kind)
+    unet = model.model.diffusion_model
+    g = np.load(os.path.join(G, kind + ".npz"))
+    inp = inputs(kind, 2)
+    t = torch.tensor([981, 401])
+    cond = {"c_crossattn": inp["c_crossattn"].cuda(), "c_concat": [inp["c_concat"].cuda()]}
+    out = {}
+    try:
+        for mode in ("0", "1"):
+            monkeypatch.setenv("UPGPT_SKIP_FOLD", mode)
+            unet._plans.clear()
+            eps = model.apply_model(inp["x_T"].cuda(), t.cuda(), cond)
+            pl = next(iter(unet._plans.values()))
+            n_app = sum(1 for d, key in pl.convs if "_ka" in key)
+            assert n_app == (0 if mode == "0" else sum(1 for L_ in unet.arch.all_layers()
+                                                       if L_.kind == "res" and L_.cin != L_.cout))
+            assert mse(eps, g["unet_eps"]) < 1e-4
+            out[mode] = eps
+        assert n_app >= 10
+        assert mse(out["0"], out["1"].cpu()) < 1e-5
+        # sampler path (captured graph) with the fold on
+        k = KIND[kind]
+        B = 2 if kind == "tiny" else 1
+        S = 10
+        c1 = {"c_crossattn": inp["c_crossattn"][:B].cuda(), "c_concat": [inp["c_concat"][:B].cuda()]}
+        z, _ = DDIMSampler(model).sample(S=S, batch_size=B, shape=(k["C"], 32, 24), conditioning=c1, eta=0.0,
+                                         x_T=inp["x_T"][:B].cuda(), verbose=False)
+        e = mse(z, g["ddim_S10_eta0/z"])
+        print("%s skip-fold ddim_S10 latent MSE %.3e" % (kind, e))
+        assert e < 1e-3
+    finally:
+        monkeypatch.delenv("UPGPT_SKIP_FOLD", raising=False)
+        unet._plans.clear()
+
+
 @pytest.mark.parametrize("kind,S,eta", [("tiny", 10, 0.0), ("tiny", 10, 1.0), ("tiny", 50, 0.0), ("bbox", 10, 0.0),
                                         ("bbox", 10, 1.0), ("bbox", 50, 0.0), ("upscale", 10, 0.0),
                                         ("upscale", 10, 1.0)])

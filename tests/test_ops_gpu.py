@@ -116,6 +116,71 @@ def test_conv_all_configs_and_splitk(ctx):
         ctx.conv_override(-1, 0)
 
 
+@pytest.mark.parametrize("ks,c,c3,c4,cout,hw", [(3, 64, 96, 32, 224, (12, 10)), (3, 96, 64, 0, 64, (8, 8)),
+                                               (1, 64, 32, 64, 96, (9, 7)), (3, 224, 448, 224, 224, (6, 4))])
+def test_conv_with_appended_1x1_segment(ctx, ks, c, c3, c4, cout, hw):
+    """y = conv_ks(h) + conv1x1(x3 | x4) + b1 + b2 in ONE launch (include/upk.h x3/x4: the ResBlock skip projection
+    riding along the second conv, openaimodel.py:274-275) — every wave-specialised tile configuration x split-K,
+    incl. splits that start inside the appended segment; the classic kernels refuse."""
+    B = 2
+    H, W = hw
+    h = rnd(B, c, H, W, seed=1)
+    x3 = rnd(B, c3, H, W, seed=2)
+    x4 = rnd(B, c4, H, W, seed=3) if c4 else None
+    w1 = rnd(cout, c, ks, ks, scale=1 / math.sqrt(ks * ks * c), seed=4)
+    w2 = rnd(cout, c3 + c4, 1, 1, scale=1 / math.sqrt(c3 + c4), seed=5)
+    b = rnd(cout, scale=0.1, seed=6)
+    hq, x3q = h.half().float(), x3.half().float()
+    xs = x3q if x4 is None else torch.cat([x3q, x4.half().float()], 1)
+    ref = F.conv2d(hq, w1.half().float(), None, padding=ks // 2) + F.conv2d(xs, w2.half().float(), None) + b.view(1, -1, 1, 1)
+    hn, x3n = nhwc16(h), nhwc16(x3)
+    x4n = nhwc16(x4) if x4 is not None else None
+    wp1, n_pad = ctx.pack_weight(w1.contiguous())
+    wp2, n_pad2 = ctx.pack_weight(w2.contiguous())
+    assert n_pad == n_pad2
+    wp = torch.cat([wp1.reshape(-1), wp2.reshape(-1)])
+    res = rnd(B, H, W, cout, seed=7).half()
+    ncfg = ctx.lib.upk_conv_num_configs()
+    ran = refused = 0
+    try:
+        for cfg in range(ncfg):
+            for sk in (1, 2, 5):
+                y = torch.zeros(B, H, W, cout, device=DEV, dtype=torch.float16)
+                d = make_desc(ctx, hn, w1, b, y, residual=res if cfg % 2 else None)
+                d.w_packed = wp.data_ptr()
+                d.x3, d.c3, d.ld3 = x3n.data_ptr(), c3, c3
+                if x4n is not None:
+                    d.x4, d.c4, d.ld4 = x4n.data_ptr(), c4, c4
+                ctx.conv_override(cfg, sk)
+                name = ctx.lib.upk_conv_config_name(cfg).decode()
+                try:
+                    ctx.conv(d)
+                except RuntimeError:
+                    refused += 1  # classic (register-staged) kernels, or a split finer than the K loop allows
+                    continue
+                torch.cuda.synchronize()
+                want = ref + (res.float().permute(0, 3, 1, 2) if cfg % 2 else 0)
+                check(y.permute(0, 3, 1, 2), want)
+                assert "w" in name, "only the wave-specialised configurations take an appended segment (%s)" % name
+                ran += 1
+    finally:
+        ctx.conv_override(-1, 0)
+    assert ran >= 25 and refused >= 35, (ran, refused)  # (a 1x1 main conv has too few chunks for split-K)
+    # cost-model choice (no override) must pick a configuration that supports it
+    y = torch.zeros(B, H, W, cout, device=DEV, dtype=torch.float16)
+    d = make_desc(ctx, hn, w1, b, y)
+    d.w_packed = wp.data_ptr()
+    d.x3, d.c3, d.ld3 = x3n.data_ptr(), c3, c3
+    if x4n is not None:
+        d.x4, d.c4, d.ld4 = x4n.data_ptr(), c4, c4
+    ctx.conv(d)
+    torch.cuda.synchronize()
+    check(y.permute(0, 3, 1, 2), ref)
+    d.stride = 2
+    with pytest.raises(RuntimeError):
+        ctx.conv(d)
+
+
 def test_conv_randomised_shapes_configs_and_epilogues(ctx):
     """Seeded sweep over ragged shapes (M not a tile multiple, N not a multiple of 16, 1x1 / 3x3, stride 2, upsample,
     concat), random tile configurations / split-K factors and epilogue combinations (bias, residual, timestep row

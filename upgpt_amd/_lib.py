@@ -57,6 +57,8 @@ class ConvDesc(C.Structure):
         ("tune_cfg", C.c_int32), ("tune_splitk", C.c_int32),
         ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_dim", C.c_int32),
         ("gn_stats_ws", C.c_void_p), ("gn_groups", C.c_int32),
+        ("x3", C.c_void_p), ("x4", C.c_void_p),
+        ("c3", C.c_int32), ("c4", C.c_int32), ("ld3", C.c_int32), ("ld4", C.c_int32),
     ]
 
 

@@ -73,7 +73,11 @@ struct IgemmArgs {
   float ln_eps;
   float ln_inv_dim;
   int cpt;         // 32-wide chunks per tap = (c1+c2)/32
-  int nchunks;     // ks*ks*cpt
+  int nchunks;     // ks*ks*cpt + appended chunks
+  int nchunks_main;  // ks*ks*cpt: the appended 1x1 segment (x3 | x4 at the output pixel) starts here
+  const f16* x3;
+  const f16* x4;
+  int c3, c4, ld3, ld4;
   int chunks_per_split;
   int tiles_m, tiles_n;
   int flags;
@@ -702,7 +706,10 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
 }
 
-template <int MI, int NI, int WM, int WN, int KS, int NBUF>
+// APP: the loader also walks the appended 1x1 K segment (IgemmArgs::x3 | x4).  A separate instantiation: the loader
+// waves set the fill rate of the K loop, and even the few extra scalar registers of the switch-over cost 1.8 % of a
+// UNet forward when they sat in the common kernels.
+template <int MI, int NI, int WM, int WN, int KS, int NBUF, bool APP = false>
 __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
   // WM*WN == 4: the 4 MFMA waves tile the block in M x N (each a MI x NI register tile).
   // WM*WN == 1: K-SPLIT mode — every MFMA wave owns the WHOLE MI x NI block tile and takes every
@@ -776,18 +783,18 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
         a_ox[i] = (p - oy * a.Wo) * a.stride - a.pad_lo;
       }
     }
-    const int ctot = a.c1 + a.c2;
     int cur_kc = kc0, cur_c0, cur_ky, cur_kx;
-    {
-      const int tap = kc0 / a.cpt;
-      cur_c0 = (kc0 - tap * a.cpt) * 32;
-      cur_ky = tap / a.ks;
-      cur_kx = tap - cur_ky * a.ks;
-    }
     const f16* ap1[AGW];
     const f16* ap2[AGW];
     bool tap_ok[AGW];
+    // APP: the current source pair is (x1 | x2) over the ks x ks taps, then (x3 | x4) at the output pixel
+    bool in_app = false;
     auto set_tap = [&](int ky, int kx) {
+      const f16* sx1 = (APP && in_app) ? a.x3 : a.x1;
+      const f16* sx2 = (APP && in_app) ? a.x4 : a.x2;
+      const int sc1 = (APP && in_app) ? a.c3 : a.c1;
+      const int sld1 = (APP && in_app) ? a.ld3 : a.ld1;
+      const int sld2 = (APP && in_app) ? a.ld4 : a.ld2;
 #pragma unroll
       for (int i = 0; i < AGW; ++i) {
         int iy = a_oy[i] + ky;
@@ -798,11 +805,29 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
           ix >>= 1;
         }
         const long pix = tap_ok[i] ? ((long)a_b[i] * a.HS + iy) * a.WS + ix : 0;
-        ap1[i] = a.x1 + pix * a.ld1 + chd * 8;
-        ap2[i] = a.x2 ? a.x2 + pix * a.ld2 + chd * 8 - a.c1 : a.x1;
+        ap1[i] = sx1 + pix * sld1 + chd * 8;
+        ap2[i] = sx2 ? sx2 + pix * sld2 + chd * 8 - sc1 : sx1;
       }
     };
-    set_tap(cur_ky, cur_kx);
+    int sc1 = a.c1;            // channels of the first source of the current pair
+    int ctot = a.c1 + a.c2;    // channels of the current pair
+    auto enter_append = [&]() {  // stride 1, no upsample: tap (pad_lo, pad_lo) is the output pixel itself
+      in_app = true;
+      sc1 = a.c3;
+      ctot = a.c3 + a.c4;
+      set_tap(a.pad_lo, a.pad_lo);
+    };
+    if (APP && kc0 >= a.nchunks_main) {
+      cur_c0 = (kc0 - a.nchunks_main) * 32;
+      cur_ky = cur_kx = 0;
+      enter_append();
+    } else {
+      const int tap = kc0 / a.cpt;
+      cur_c0 = (kc0 - tap * a.cpt) * 32;
+      cur_ky = tap / a.ks;
+      cur_kx = tap - cur_ky * a.ks;
+      set_tap(cur_ky, cur_kx);
+    }
     // B rows of this lane
     const f16* bp[BGW];
     bool b_ok[BGW];
@@ -823,7 +848,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const bool live = cur_kc < kc1;
-        const bool second = cur_c0 >= a.c1;
+        const bool second = cur_c0 >= sc1;
 #pragma unroll
         for (int i = 0; i < AGW; ++i) {
           const int rg = lw + 4 * i;  // wave-uniform
@@ -847,7 +872,10 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
             cur_kx = 0;
             ++cur_ky;
           }
-          if (cur_kc < kc1) set_tap(cur_ky, cur_kx);
+          if (cur_kc < kc1) {
+            if (APP && cur_kc == a.nchunks_main) enter_append();
+            else set_tap(cur_ky, cur_kx);
+          }
         }
       }
     };
@@ -1253,12 +1281,14 @@ struct CfgInfo {
   const char* name;
   void (*fn)(const IgemmArgs);
   int nbuf;  // 0: classic register-staged kernel; > 0: wave-specialised DMA kernel (512 threads)
+  void (*fn_app)(const IgemmArgs);  // variant whose loader walks an appended 1x1 K segment, or nullptr
 };
 
 #define CFG(MI, NI, WM, WN, KS) \
-  {MI, NI, WM, WN, KS, #MI "x" #NI "x" #WM "x" #WN "k" #KS, igemm_kernel<MI, NI, WM, WN, KS>, 0}
+  {MI, NI, WM, WN, KS, #MI "x" #NI "x" #WM "x" #WN "k" #KS, igemm_kernel<MI, NI, WM, WN, KS>, 0, nullptr}
 #define CFGW(MI, NI, WM, WN, KS, NB) \
-  {MI, NI, WM, WN, KS, #MI "x" #NI "x" #WM "x" #WN "k" #KS "w" #NB, igemm_ws_kernel<MI, NI, WM, WN, KS, NB>, NB}
+  {MI, NI, WM, WN, KS, #MI "x" #NI "x" #WM "x" #WN "k" #KS "w" #NB, igemm_ws_kernel<MI, NI, WM, WN, KS, NB>, NB, \
+   igemm_ws_kernel<MI, NI, WM, WN, KS, NB, true>}
 // (MI, NI, WM, WN, KS): block tile = (MI*16*WM) x (NI*16*WN), WM*WN waves, KS K-chunks/stage.
 const CfgInfo kCfgs[] = {
     CFG(4, 4, 2, 2, 1), CFG(4, 4, 2, 2, 2),  // 128x128
@@ -1422,7 +1452,22 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   if (a.ln_u && (!a.linear || d->c2 != 0 || d->ln_dim <= 0 || d->ln_dim > d->c1))
     return upk_fail(ctx, UPK_EINVAL, "conv: folded LayerNorm needs a 1x1 stride-1 single-source launch, 0 < ln_dim <= c1");
   a.cpt = (a.c1 + a.c2) / 32;
-  a.nchunks = a.ks * a.ks * a.cpt;
+  a.nchunks_main = a.ks * a.ks * a.cpt;
+  a.nchunks = a.nchunks_main;
+  if (d->x3) {
+    if (d->c3 <= 0 || (d->c3 & 31) || d->c4 < 0 || (d->c4 & 31) || (d->c4 > 0 && !d->x4) || (d->ld3 & 7) ||
+        (d->c4 && (d->ld4 & 7)))
+      return upk_fail(ctx, UPK_ESHAPE, "conv: appended segment needs c3, c4 multiples of 32 and ld3, ld4 of 8");
+    if (d->stride != 1 || a.ups || (flags & UPK_F_PAD_ASYM) || a.ln_u)
+      return upk_fail(ctx, UPK_ESHAPE, "conv: appended 1x1 segment needs stride 1, no upsample, no folded LayerNorm");
+    a.x3 = (const f16*)d->x3;
+    a.x4 = d->c4 > 0 ? (const f16*)d->x4 : nullptr;
+    a.c3 = d->c3;
+    a.c4 = d->c4;
+    a.ld3 = d->ld3;
+    a.ld4 = d->ld4;
+    a.nchunks += (a.c3 + a.c4) / 32;
+  }
   a.flags = flags;
   if (const char* ab = getenv("UPK_ABLATE")) a.flags |= (int)strtol(ab, nullptr, 0) & 0x3F0000;
   a.dbg = (unsigned long long*)((char*)ctx->ws + ctx->ws_bytes - 4096);
@@ -1438,6 +1483,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     if (want_cfg >= 0 && c != want_cfg) continue;
     // folded LayerNorm: row statistics come from the M x N-split wave-specialised kernels, whole K in one block
     if (a.ln_u && !(kCfgs[c].nbuf && kCfgs[c].wm * kCfgs[c].wn > 1)) continue;
+    if (a.x3 && !kCfgs[c].fn_app) continue;  // the appended K segment lives in the wave-specialised loader
     for (int sk : sk_cands) {
       if (want_sk > 0 && sk != want_sk) continue;
       if (a.ln_u && sk > 1) continue;
@@ -1499,7 +1545,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
 #endif
   upk_prof_scope prof(ctx, UPK_CLS_IGEMM, stream);
   dim3 grid(a.tiles_m * a.tiles_n, 1, zdim);
-  hipLaunchKernelGGL(c.fn, grid, dim3(c.nbuf ? 512 : c.wm * c.wn * 64), 0, stream, a);
+  hipLaunchKernelGGL(a.x3 ? c.fn_app : c.fn, grid, dim3(c.nbuf ? 512 : c.wm * c.wn * 64), 0, stream, a);
   int rc = upk_check_launch(ctx, "igemm");
   if (rc) return rc;
   if (zdim > 1 && gn_fuse) {

@@ -92,7 +92,7 @@ class Act:
 
 class PW:
     """A packed weight: fp16 tiles + fp32 bias in packed row order."""
-    __slots__ = ("w", "n_pad", "bias", "n_out", "k_packed", "ksize", "n_real", "k_real", "ln_colsum")
+    __slots__ = ("w", "n_pad", "bias", "n_out", "k_packed", "ksize", "n_real", "k_real", "ln_colsum", "k_append")
 
 
 class Packer:
@@ -141,6 +141,7 @@ class Packer:
 
         p.bias = None
         p.ln_colsum = None
+        p.k_append = 0
         b = None
         if bias:
             bs = [self.get(n + ".bias") for n in names]
@@ -150,6 +151,20 @@ class Packer:
             p.ln_colsum = rows_packed(w.half().float().sum(dim=1))
         if b is not None:
             p.bias = rows_packed(b)
+        return p
+
+    def append_1x1(self, main, skip):
+        """`main` followed along K by the 1x1 weight `skip` (include/upk.h: appended K segment): one launch computes
+        conv(main) + conv1x1(skip) — a ResBlock's second conv plus its skip projection (openaimodel.py:274-275)."""
+        assert skip.ksize == 1 and skip.n_pad == main.n_pad and skip.n_out == main.n_out and main.ln_colsum is None
+        p = PW()
+        p.w = torch.cat([main.w.reshape(-1), skip.w.reshape(-1)])
+        p.n_pad, p.n_out, p.ksize, p.k_packed, p.n_real = main.n_pad, main.n_out, main.ksize, main.k_packed, main.n_real
+        p.k_append = skip.k_packed
+        p.k_real = main.k_real + skip.k_real
+        p.ln_colsum = None
+        bs = [b for b in (main.bias, skip.bias) if b is not None]
+        p.bias = None if not bs else (bs[0] if len(bs) == 1 else bs[0] + bs[1])
         return p
 
     def vec(self, name):
@@ -243,10 +258,30 @@ class Emitter:
             self.ctx._chk(rc)
 
     @staticmethod
-    def conv_key(M, n_pad, c1, c2, ks, stride, flags, has_res, has_rowvec, has_vt, ln, gs=False):
+    def conv_key(M, n_pad, c1, c2, ks, stride, flags, has_res, has_rowvec, has_vt, ln, gs=False, ka=0):
         """Shape signature of one conv/GEMM launch = key of the tuning cache."""
-        return "M%d_N%d_C%d+%d_k%ds%d_f%x_r%d%d%d%s%s" % (M, n_pad, c1, c2, ks, stride, flags, has_res, has_rowvec,
-                                                         has_vt, "_ln" if ln else "", "_gs" if gs else "")
+        return "M%d_N%d_C%d+%d_k%ds%d_f%x_r%d%d%d%s%s%s" % (M, n_pad, c1, c2, ks, stride, flags, has_res, has_rowvec,
+                                                           has_vt, "_ln" if ln else "", "_gs" if gs else "",
+                                                           "_ka%d" % ka if ka else "")
+
+    def fold_skip(self, hN, pw_main, pw_skip, x, skip):
+        """Whether a ResBlock's 1x1 skip projection rides along its second conv as an appended K segment
+        (include/upk.h x3/x4).  UPGPT_SKIP_FOLD=0/1 forces it; by default the tuning cache decides: fused launch vs
+        conv (with residual) + skip conv, both measured by scripts/tune.py; unknown shapes keep two launches."""
+        mode = os.environ.get("UPGPT_SKIP_FOLD", "auto")
+        if mode != "auto":
+            return mode == "1"
+        c3, c4 = _rup(x.C, 32), (_rup(skip.C, 32) if skip is not None else 0)
+        base = (hN.M, pw_main.n_pad, _rup(hN.C, 32), 0, pw_main.ksize, 1, 0)
+        def tuned(key):  # (a launch whose output feeds a GroupNorm is tuned under its "_gs" name)
+            return TUNE_CACHE.get(key + "_gs") or TUNE_CACHE.get(key)
+
+        e_f = tuned(self.conv_key(*base, False, False, False, False, ka=c3 + c4))
+        e_m = tuned(self.conv_key(*base, True, False, False, False))
+        e_s = tuned(self.conv_key(hN.M, pw_skip.n_pad, c3, c4, 1, 1, 0, False, False, False, False))
+        if e_f is None or e_m is None or e_s is None:
+            return False
+        return e_f[2] < e_m[2] + e_s[2]
 
     def ln_linear(self, P, x, name, norm, flags=0, **kw):
         """LayerNorm `norm` followed by the Linear `name`: either one launch with the norm folded into the
@@ -270,7 +305,7 @@ class Emitter:
 
     def conv(self, P, x1, pw, *, x2=None, stride=1, flags=0, residual=None, rowvec=None, rv_bs=0, rv_ss=0,
              step=None, out=None, vt=None, nchw_out=None, out_f32=None, spatial=None, ln_eps=None,
-             gn_stats=False):
+             gn_stats=False, append=None):
         """Emits one upk_conv2d_nhwc_f16. Returns the output Act (fp16) unless nchw_out /
         out_f32 is given."""
         B, H, W = spatial if spatial is not None else (x1.B, x1.H, x1.W)
@@ -339,11 +374,22 @@ class Emitter:
             d.ln_colsum = pw.ln_colsum.data_ptr()
             d.ln_eps = float(ln_eps)
             d.ln_dim = x1.C
+        x3 = x4 = None
+        if append is not None:  # appended 1x1 K segment over (x3 | x4) at the output pixel; pw from Packer.append_1x1
+            x3, x4 = append
+            assert stride == 1 and not ups and (x3.B, x3.H, x3.W) == (B, Ho, Wo)
+            d.x3, d.c3, d.ld3 = x3.t.data_ptr(), _rup(x3.C, 32), x3.ld
+            if x4 is not None:
+                d.x4, d.c4, d.ld4 = x4.t.data_ptr(), _rup(x4.C, 32), x4.ld
+            assert d.c3 + d.c4 == pw.k_append, ("appended K mismatch", d.c3, d.c4, pw.k_append)
+        else:
+            assert not pw.k_append
         self.convs.append((d, self.conv_key(M, pw.n_pad, d.c1, d.c2, ks, stride, flags, residual is not None,
-                                            rowvec is not None, vt is not None, ln_eps is not None)))
+                                            rowvec is not None, vt is not None, ln_eps is not None,
+                                            ka=d.c3 + d.c4)))
         fn, h, ref = self.lib.upk_conv2d_nhwc_f16, self.hctx, C.byref(d)
         chk = self._chk
-        P.add(lambda s: chk(fn(h, ref, s)), d, pw, x1, x2, residual, rowvec, out, nchw_out, out_f32, vt,
+        P.add(lambda s: chk(fn(h, ref, s)), d, pw, x1, x2, x3, x4, residual, rowvec, out, nchw_out, out_f32, vt,
               cls="igemm_k%d" % ks)
         P.igemm_flops += 2 * M * pw.n_real * pw.k_real
         return ret
@@ -449,6 +495,7 @@ class PackedUNet:
                 w[n + ".out_layers.3"] = pk.pack(n + ".out_layers.3")
                 if Lr.cin != Lr.cout:
                     w[n + ".skip_connection"] = pk.pack(n + ".skip_connection")
+                    w[n + ".out_layers.3+skip"] = pk.append_1x1(w[n + ".out_layers.3"], w[n + ".skip_connection"])
             elif Lr.kind == "st":
                 if Lr.depth != 1:
                     raise NotImplementedError("transformer_depth != 1")
@@ -569,6 +616,9 @@ class UNetPlan(Emitter):
         g, b = v[n + ".out_layers.0"]
         hN = self.groupnorm(P, hh, g, b, 1e-5, True, self.gn_ws)
         if Lr.cin != Lr.cout:
+            if self.fold_skip(hN, w[n + ".out_layers.3"], w[n + ".skip_connection"], x, skip):
+                # skip projection as an appended K segment of the second conv: one launch, no residual round trip
+                return self.conv(P, hN, w[n + ".out_layers.3+skip"], append=(x, skip), gn_stats=True)
             sk = self.conv(P, x, w[n + ".skip_connection"], x2=skip)
         else:
             assert skip is None
