@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of the appended-K-segment change: old library vs new library (fold off) vs new library + tuned fold.
+# (needs the PREVIOUS build of the library saved as scripts/ab/libupk_old.so before rebuilding; git-ignored)
 mkdir -p gpurun_out; export TMPDIR=/tmp
 F='^DDIM\|Running in\|params\.\|Keeping\|Data shape\|Running DDIM\|Plotting'
 fwd() { python -c "import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[1], 'img/s %.2f fwd_ms %.4f' % (d['value'], d['unet']['fwd_ms_graph']), d['unet']['class_ms_per_fwd'])" $1; }
