@@ -56,6 +56,7 @@ for kind in kinds:
             else:
                 os.environ["UPGPT_LN_FOLD"] = fold
             os.environ["UPGPT_SKIP_FOLD"] = skf
+            os.environ["UPGPT_FFOUT_FOLD"] = skf  # (ff.net.2 + proj_out as one GEMM: measured in the same variant)
             unet._plans.clear()
             t0 = time.time()
             pl = unet.plan(B, H, W, ntok, S, "sampler")
@@ -64,6 +65,7 @@ for kind in kinds:
             TUNE_CACHE.save(out)
         os.environ.pop("UPGPT_LN_FOLD", None)
         os.environ.pop("UPGPT_SKIP_FOLD", None)
+        os.environ.pop("UPGPT_FFOUT_FOLD", None)
         unet._plans.clear()
         t0 = time.time()
         vp = model.first_stage_model._decode_plan(B, H, W, 0.18215)

@@ -68,8 +68,9 @@ def test_unet_forward_vs_reference_golden_and_oracle(kind):
 @pytest.mark.parametrize("kind", ["tiny", "bbox", "upscale"])
 def test_skip_projection_folded_into_second_conv_vs_reference_golden(kind, monkeypatch):
     """UPGPT_SKIP_FOLD=1: every ResBlock whose channel count changes runs its 1x1 skip projection as an appended K
-    segment of its second conv (include/upk.h x3/x4) — same goldens, same tolerances; and the folded and the
-    two-launch programs agree to fp16 rounding (the fold drops the fp16 round trip of the skip tensor)."""
+    segment of its second conv (include/upk.h x3/x4); UPGPT_FFOUT_FOLD=1: every SpatialTransformer runs ff.net.2 and
+    proj_out as one GEMM over [ff | t2] with the pre-multiplied weight — same goldens, same tolerances; the folded
+    and the unfolded programs agree to fp16 rounding (the folds drop fp16 round trips of intermediate tensors)."""
     model, _ = get_model(kind)
     unet = model.model.diffusion_model
     g = np.load(os.path.join(G, kind + ".npz"))
@@ -80,15 +81,16 @@ def test_skip_projection_folded_into_second_conv_vs_reference_golden(kind, monke
     try:
         for mode in ("0", "1"):
             monkeypatch.setenv("UPGPT_SKIP_FOLD", mode)
+            monkeypatch.setenv("UPGPT_FFOUT_FOLD", mode)
             unet._plans.clear()
             eps = model.apply_model(inp["x_T"].cuda(), t.cuda(), cond)
             pl = next(iter(unet._plans.values()))
             n_app = sum(1 for d, key in pl.convs if "_ka" in key)
             assert n_app == (0 if mode == "0" else sum(1 for L_ in unet.arch.all_layers()
-                                                       if L_.kind == "res" and L_.cin != L_.cout))
+                                                       if (L_.kind == "res" and L_.cin != L_.cout) or L_.kind == "st"))
             assert mse(eps, g["unet_eps"]) < 1e-4
             out[mode] = eps
-        assert n_app >= 10
+        assert n_app >= 25
         assert mse(out["0"], out["1"].cpu()) < 1e-5
         # sampler path (captured graph) with the fold on
         k = KIND[kind]
@@ -102,6 +104,7 @@ def test_skip_projection_folded_into_second_conv_vs_reference_golden(kind, monke
         assert e < 1e-3
     finally:
         monkeypatch.delenv("UPGPT_SKIP_FOLD", raising=False)
+        monkeypatch.delenv("UPGPT_FFOUT_FOLD", raising=False)
         unet._plans.clear()
 
 

@@ -167,6 +167,16 @@ class Packer:
         p.bias = None if not bs else (bs[0] if len(bs) == 1 else bs[0] + bs[1])
         return p
 
+    def pack_product(self, outer, inner):
+        """The Linear `inner` followed by the Linear / 1x1 conv `outer` with nothing in between, as ONE weight:
+        W = W_outer @ W_inner (fp32, then packed fp16), bias = W_outer @ b_inner (`outer`'s own bias is left to the
+        caller: Packer.append_1x1 adds it with the appended segment)."""
+        wo = self.get(outer + ".weight").float()
+        wo = wo.reshape(wo.shape[0], -1)
+        wi = self.get(inner + ".weight").float()
+        prod = {"p.weight": (wo @ wi).contiguous(), "p.bias": wo @ self.get(inner + ".bias").float()}
+        return Packer(self.ctx, lambda n: prod[n]).pack("p")
+
     def vec(self, name):
         return self.get(name).float().contiguous()
 
@@ -282,6 +292,26 @@ class Emitter:
         if e_f is None or e_m is None or e_s is None:
             return False
         return e_f[2] < e_m[2] + e_s[2]
+
+    def fold_ff_out(self, ff, t2, pw_ff):
+        """Whether a SpatialTransformer's last two linear maps — ff.net.2 (+ residual t2, attention.py:215) and
+        proj_out (+ residual x_in, attention.py:259-261), nothing but a reshape between them — run as one GEMM over
+        [ff | t2] with the pre-multiplied weight [P F2 | P].  UPGPT_FFOUT_FOLD=0/1 forces it; by default the tuning
+        cache decides (fused launch vs the two launches); unknown shapes keep two launches."""
+        mode = os.environ.get("UPGPT_FFOUT_FOLD", "auto")
+        if mode != "auto":
+            return mode == "1"
+
+        def tuned(key):
+            return TUNE_CACHE.get(key + "_gs") or TUNE_CACHE.get(key)
+
+        M, n_pad, c_ff, c_t = ff.M, pw_ff.n_pad, _rup(ff.C, 32), _rup(t2.C, 32)
+        e_f = tuned(self.conv_key(M, n_pad, c_ff, 0, 1, 1, 0, True, False, False, False, ka=c_t))
+        e_a = tuned(self.conv_key(M, n_pad, c_ff, 0, 1, 1, 0, True, False, False, False))
+        e_b = tuned(self.conv_key(M, n_pad, c_t, 0, 1, 1, 0, True, False, False, False))
+        if e_f is None or e_a is None or e_b is None:
+            return False
+        return e_f[2] < e_a[2] + e_b[2]
 
     def ln_linear(self, P, x, name, norm, flags=0, **kw):
         """LayerNorm `norm` followed by the Linear `name`: either one launch with the norm folded into the
@@ -525,6 +555,10 @@ class PackedUNet:
                 for k in ("norm1", "norm2", "norm3"):
                     norm(t + "." + k)
                 w[n + ".proj_out"] = pk.pack(n + ".proj_out")
+                # proj_out(t2 + ff.net.2(h)) = (P F2) h + P t2 + (P b2 + bp): the block's last Linear and the
+                # transformer's output projection as one GEMM with t2 as an appended K segment (Emitter.fold_ff_out)
+                w[n + ".ff.out+proj_out"] = pk.append_1x1(pk.pack_product(n + ".proj_out", t + ".ff.net.2"),
+                                                          w[n + ".proj_out"])
             elif Lr.kind == "down":
                 w[n + ".op"] = pk.pack(n + ".op")
             elif Lr.kind == "up":
@@ -658,6 +692,8 @@ class UNetPlan(Emitter):
         t2 = self.conv(P, a2, w[t + ".attn2.to_out"], residual=t1)
         # GEGLU feed-forward
         ff = self.ln_linear(P, t2, t + ".ff.geglu", t + ".norm3", flags=L.F_GEGLU)
+        if self.fold_ff_out(ff, t2, w[t + ".ff.out"]):
+            return self.conv(P, ff, w[n + ".ff.out+proj_out"], residual=x, append=(t2, None), gn_stats=True)
         t3 = self.conv(P, ff, w[t + ".ff.out"], residual=t2)
         return self.conv(P, t3, w[n + ".proj_out"], residual=x, gn_stats=True)
 
