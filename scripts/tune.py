@@ -38,7 +38,7 @@ def summarize(name, emitter):
 
 for kind in kinds:
     with contextlib.redirect_stdout(io.StringIO()):
-        model = upgpt_amd.build_model("bbox" if kind == "bbox_cfg" else kind)
+        model = upgpt_amd.build_model("bbox" if kind in ("bbox_cfg", "bbox_small") else kind)
     synth.fill_module_(model)
     model = model.cuda()
     unet = model.model.diffusion_model
@@ -47,6 +47,8 @@ for kind in kinds:
     shapes = [(8, 32, 32, 50), (8, 32, 24, 50)] if kind == "bbox" else [(4, 64, 64, 50)]
     if kind == "bbox_cfg":  # classifier-free guidance runs the UNet on 2*B rows
         shapes, kind = [(16, 32, 32, 50), (16, 32, 24, 50)], "bbox"
+    if kind == "bbox_small":  # the demo's batch sizes (app.py: 1 sample, interpolation rows of 2-4), 256x192
+        shapes, kind = [(1, 32, 24, 50), (2, 32, 24, 50), (4, 32, 24, 50)], "bbox"
     for (B, H, W, S) in shapes:
         # LayerNorm folded into its consumer GEMM / separate, ResBlock skip projection appended to the second conv /
         # separate: every variant gets measured, the emitter then picks per shape
