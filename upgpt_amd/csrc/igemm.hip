@@ -709,7 +709,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 // APP: the loader also walks the appended 1x1 K segment (IgemmArgs::x3 | x4).  A separate instantiation: the loader
 // waves set the fill rate of the K loop, and even the few extra scalar registers of the switch-over cost 1.8 % of a
 // UNet forward when they sat in the common kernels.
-template <int MI, int NI, int WM, int WN, int KS, int NBUF, bool APP = false>
+// LNF: the MFMA waves also take the folded LayerNorm's row statistics (IgemmArgs::ln_u) — likewise its own
+// instantiation (M x N split configurations only): a wave-uniform test per K chunk and 2*MI live registers less in
+// the kernels every other launch uses.
+template <int MI, int NI, int WM, int WN, int KS, int NBUF, bool APP = false, bool LNF = false>
 __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
   // WM*WN == 4: the 4 MFMA waves tile the block in M x N (each a MI x NI register tile).
   // WM*WN == 1: K-SPLIT mode — every MFMA wave owns the WHOLE MI x NI block tile and takes every
@@ -928,7 +931,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
 
   // folded LayerNorm (M x N split only): per-row sum / sum of squares of the A fragments this wave
   // reads anyway; lane (lc, lg) sees row lc, k-slice lg of every chunk
-  const bool ln = a.ln_u != nullptr;
+  constexpr bool ln = LNF;
   float ln_s1[MI], ln_s2[MI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) ln_s1[i] = ln_s2[i] = 0.f;
@@ -1282,13 +1285,20 @@ struct CfgInfo {
   void (*fn)(const IgemmArgs);
   int nbuf;  // 0: classic register-staged kernel; > 0: wave-specialised DMA kernel (512 threads)
   void (*fn_app)(const IgemmArgs);  // variant whose loader walks an appended 1x1 K segment, or nullptr
+  void (*fn_ln)(const IgemmArgs);   // variant whose MFMA waves take the folded LayerNorm's row statistics, or nullptr
 };
 
+template <int MI, int NI, int WM, int WN, int KS, int NB>
+constexpr void (*ws_ln_fn())(const IgemmArgs) {
+  if constexpr (WM * WN > 1) return igemm_ws_kernel<MI, NI, WM, WN, KS, NB, false, true>;
+  else return nullptr;
+}
+
 #define CFG(MI, NI, WM, WN, KS) \
-  {MI, NI, WM, WN, KS, #MI "x" #NI "x" #WM "x" #WN "k" #KS, igemm_kernel<MI, NI, WM, WN, KS>, 0, nullptr}
+  {MI, NI, WM, WN, KS, #MI "x" #NI "x" #WM "x" #WN "k" #KS, igemm_kernel<MI, NI, WM, WN, KS>, 0, nullptr, nullptr}
 #define CFGW(MI, NI, WM, WN, KS, NB) \
   {MI, NI, WM, WN, KS, #MI "x" #NI "x" #WM "x" #WN "k" #KS "w" #NB, igemm_ws_kernel<MI, NI, WM, WN, KS, NB>, NB, \
-   igemm_ws_kernel<MI, NI, WM, WN, KS, NB, true>}
+   igemm_ws_kernel<MI, NI, WM, WN, KS, NB, true>, ws_ln_fn<MI, NI, WM, WN, KS, NB>()}
 // (MI, NI, WM, WN, KS): block tile = (MI*16*WM) x (NI*16*WN), WM*WN waves, KS K-chunks/stage.
 const CfgInfo kCfgs[] = {
     CFG(4, 4, 2, 2, 1), CFG(4, 4, 2, 2, 2),  // 128x128
@@ -1482,7 +1492,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   for (int c = 0; c < kNumCfgs; ++c) {
     if (want_cfg >= 0 && c != want_cfg) continue;
     // folded LayerNorm: row statistics come from the M x N-split wave-specialised kernels, whole K in one block
-    if (a.ln_u && !(kCfgs[c].nbuf && kCfgs[c].wm * kCfgs[c].wn > 1)) continue;
+    if (a.ln_u && !kCfgs[c].fn_ln) continue;
     if (a.x3 && !kCfgs[c].fn_app) continue;  // the appended K segment lives in the wave-specialised loader
     for (int sk : sk_cands) {
       if (want_sk > 0 && sk != want_sk) continue;
@@ -1545,7 +1555,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
 #endif
   upk_prof_scope prof(ctx, UPK_CLS_IGEMM, stream);
   dim3 grid(a.tiles_m * a.tiles_n, 1, zdim);
-  hipLaunchKernelGGL(a.x3 ? c.fn_app : c.fn, grid, dim3(c.nbuf ? 512 : c.wm * c.wn * 64), 0, stream, a);
+  hipLaunchKernelGGL(a.ln_u ? c.fn_ln : (a.x3 ? c.fn_app : c.fn), grid, dim3(c.nbuf ? 512 : c.wm * c.wn * 64), 0, stream, a);
   int rc = upk_check_launch(ctx, "igemm");
   if (rc) return rc;
   if (zdim > 1 && gn_fuse) {
