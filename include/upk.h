@@ -159,6 +159,27 @@ typedef struct upk_conv_desc {
   const void* x4;
   int32_t c3, c4;
   int32_t ld3, ld4;
+  /* A-stationary "patch" kernel (csrc/pconv.hip), selected with pc_enable != 0 (stride 1, no upsample, no split-K,
+   * no folded LayerNorm): an M tile = whole output image rows of ONE sample; its input patch (+ the 3x3 halo) is
+   * staged once in LDS through registers and the MFMA waves walk the ksize^2 taps out of LDS while only the weights
+   * stream through the LDS-DMA ring (one fill per input pixel instead of nine).  pc_cfg - 1 = tile configuration
+   * (0: built-in choice), upk_pconv_num_configs / upk_pconv_config_name enumerate them.
+   * GroupNorm (+ SiLU) of the INPUT folded into the staging pass — ResBlock in_layers / out_layers
+   * (openaimodel.py:255-275: GroupNorm32 -> SiLU -> conv3x3), SpatialTransformer.norm -> proj_in
+   * (attention.py:250-256):  x1 | x2 are the UN-normalised tensors, gni_gamma / gni_beta the affine over the
+   * c1 + c2 concatenated channels, and the statistics come from partial sums a producer left behind:
+   *   gni_mode 1: per-(chunk, group) partials [batch][gni_nblk1][gni_groups][2] as upk_groupnorm_nhwc_f16's first
+   *               pass / a split-K reduce pass write them (any number of sources);
+   *   gni_mode 2: per-(row block, channel) partials [batch][nblk][2][ld] of each source's producer epilogue.
+   * Zero padding is applied AFTER the normalisation, as F.conv2d on the normalised tensor does. */
+  int32_t pc_enable, pc_cfg;
+  int32_t gni_mode, gni_silu, gni_groups;
+  float gni_eps;
+  const float* gni_gamma;
+  const float* gni_beta;
+  const float* gni_stats1;
+  const float* gni_stats2;
+  int32_t gni_nblk1, gni_ld1, gni_nblk2, gni_ld2;
 } upk_conv_desc;
 
 /* Replaces F.conv2d (3x3 s1/s2 p1, 1x1) / F.linear call sites:
@@ -172,6 +193,13 @@ int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream)
 /* Which GroupNorm by-product upk_conv2d_nhwc_f16(d) will leave in d->gn_stats_ws (see upk_conv_desc): *mode in
  * {0, 1, 2}, *nblk = row blocks per sample for mode 2.  Nothing is enqueued. */
 int upk_conv_gn_fused(upk_ctx* ctx, const upk_conv_desc* d, int* mode, int* nblk);
+
+/* Tile configurations of the A-stationary patch kernel (upk_conv_desc.pc_enable / pc_cfg). */
+int upk_pconv_num_configs(void);
+const char* upk_pconv_config_name(int cfg);
+/* 1 if upk_conv2d_nhwc_f16 would run `d` on the patch kernel (with d->pc_enable set), 0 if the shape is outside
+ * its domain (the launch then falls back to the implicit-GEMM kernels and REFUSES gni_mode != 0). */
+int upk_pconv_supported(upk_ctx* ctx, const upk_conv_desc* d);
 
 /* Convenience wrapper: y[M,N] = act(A[M,K] @ W^T + bias) + residual. */
 int upk_gemm_f16(upk_ctx* ctx, const void* a, int lda, int m, int k, const void* w_packed,
@@ -248,6 +276,12 @@ int upk_groupnorm_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int ld1, const 
                            const float* beta, float eps, int fuse_silu, void* y, int ldy,
                            float* stats_ws, upk_stream stream);
 size_t upk_groupnorm_ws_bytes(int batch, int hw);
+/* First half of upk_groupnorm_nhwc_f16 only: the per-(chunk, group) partial sums [batch][nchunks][groups][2]
+ * (nchunks = *nchunks of upk_groupnorm_chunks(hw)) for a consumer that normalises on the fly
+ * (upk_conv_desc.gni_mode 1). */
+int upk_groupnorm_stats_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* x2, int c2, int ld2,
+                                 int batch, int hw, int groups, float* stats_ws, upk_stream stream);
+int upk_groupnorm_chunks(int hw);
 /* Second half of upk_groupnorm_nhwc_f16 only: stats_ws already holds the partial sums of x1, left by the conv
  * launch that produced it (upk_conv_desc.gn_stats_ws): stats_mode / stats_nblk as reported by upk_conv_gn_fused,
  * stats_ld = that launch's n_pad.  A two-source (concat) input needs mode 2 for BOTH sources: stats_ws2 /

@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libupk.so")
-SOURCES = ["igemm.hip", "attention.hip", "norm.hip", "misc.hip"]
+SOURCES = ["igemm.hip", "pconv.hip", "attention.hip", "norm.hip", "misc.hip"]
 ARCH = "gfx950"
 
 

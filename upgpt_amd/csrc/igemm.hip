@@ -18,448 +18,11 @@
 //     deterministic reduce+epilogue kernel (deep UNet levels have M = 96..384 rows only).
 //
 // Replaces F.conv2d / F.linear at the call sites listed in include/upk.h.
-#include <stdlib.h>
-
-#include "common.h"
+#include "igemm_common.h"
 
 namespace {
+using namespace upkd;
 
-// debug-only ablation bits (env UPK_ABLATE, read per launch): which phase owns the time?
-enum {
-  ABL_NOEPI = 0x10000,
-  ABL_NOGLOAD = 0x20000,
-  ABL_NOLDSW = 0x40000,
-  ABL_NOMFMA = 0x80000,
-  ABL_EMPTY = 0x100000,  // WS kernel returns at entry (pure launch cost of its geometry)
-  ABL_TIMELINE = 0x200000,  // WS kernel: blocks 0 and gridDim.x-1 write s_memtime stamps to the workspace
-};
-// The ablation / timeline hooks are compiled in only for dev builds (UPK_CXXFLAGS=-DUPK_DEV, scripts/ablate.sh,
-// scripts/timeline*.py): even as never-taken runtime tests they cost scalar registers and instructions in the loops.
-#if defined(UPK_DEV) || defined(UPK_TIMELINE)
-#define ABL_ON(f) ((a.flags & (f)) != 0)
-#else
-#define ABL_ON(f) (false)
-#endif
-
-
-struct IgemmArgs {
-  const f16* x1;
-  const f16* x2;
-  int c1, c2, ld1, ld2;
-  const f16* w;
-  const f16* zero;  // zero page (device)
-  int npad;
-  const float* bias;
-  const f16* res;
-  int ldr;
-  const float* rowvec;
-  int rv_bs, rv_ss;
-  const int* step;
-  void* y;
-  int ldy;
-  f16* vt;
-  int vt_from, vt_heads, vt_dhead, vt_ld, vt_tokens;
-  float* partial;  // split-K slabs [splitk][M][npad] fp32, or nullptr
-  int M, n_out;
-  int B, HS, WS;   // stored input dims
-  int HL, WL;      // logical input dims (after optional 2x upsample)
-  int Ho, Wo;
-  int ks, stride, pad_lo, ups;
-  int linear;      // ks == 1 && stride == 1 && !ups: rows are addressed directly
-  unsigned long long* dbg;  // ABL_TIMELINE stamps
-  const float* ln_u;  // folded LayerNorm: column sums of the packed (gamma-scaled) weight, or nullptr
-  float* gn_cp;       // plain epilogue also writes per-(row block, channel) GroupNorm partials here, or nullptr
-  int gn_nblk, gn_hw;  // row blocks (= M tiles) per sample, pixels per sample
-  float ln_eps;
-  float ln_inv_dim;
-  int cpt;         // 32-wide chunks per tap = (c1+c2)/32
-  int nchunks;     // ks*ks*cpt + appended chunks
-  int nchunks_main;  // ks*ks*cpt: the appended 1x1 segment (x3 | x4 at the output pixel) starts here
-  const f16* x3;
-  const f16* x4;
-  int c3, c4, ld3, ld4;
-  int chunks_per_split;
-  int tiles_m, tiles_n;
-  int flags;
-};
-
-// 16-byte chunk swizzle for a [rows][4 chunks] fp16 tile (64 B rows).
-// ds_read_b128 is serviced in four 16-lane groups {0-3,12-15,20-27},{4-11,16-19,28-31},...
-// With fragment lane l reading row (l&15), chunk (l>>4), XOR-ing the chunk with
-// (-(row>>2))&3 puts the 16 lanes of every group on 16 distinct 16-B slots of the
-// 256-B bank row.
-__device__ __forceinline__ int lds_swz(int row, int chunk) { return chunk ^ ((-(row >> 2)) & 3); }
-
-// Epilogue, split in a per-ROW part (integer division for the sample index, row offsets:
-// once per 16-row fragment) and a per-4-COLUMN part, with 32-bit offsets against uniform
-// base pointers — with K loops as short as 7..16 chunks the epilogue is a large share of
-// the issued instructions, so it is kept lean.
-struct RowCtx {
-  bool ok;
-  unsigned y_off, res_off, rv_off, vt_off, nchw_off;
-};
-
-struct Epi {
-  static __device__ __forceinline__ RowCtx row(const IgemmArgs& a, int m) {
-    RowCtx r;
-    r.ok = m < a.M;
-    const int mm = r.ok ? m : 0;
-    r.y_off = (unsigned)mm * (unsigned)a.ldy;
-    r.res_off = (unsigned)mm * (unsigned)a.ldr;
-    r.rv_off = 0;
-    r.vt_off = 0;
-    r.nchw_off = 0;
-    if (a.rowvec || (a.flags & UPK_F_OUT_NCHW_F32)) {
-      const int hw = a.Ho * a.Wo;
-      const int b = mm / hw;
-      const int p = mm - b * hw;
-      const int st = (a.rowvec && a.step) ? *a.step : 0;
-      r.rv_off = (unsigned)(st * a.rv_ss + b * a.rv_bs);
-      r.nchw_off = (unsigned)(b * a.n_out * hw + p);
-    }
-    if (a.vt) {
-      const int bb = mm / a.vt_tokens;
-      const int tok = mm - bb * a.vt_tokens;
-      r.vt_off = (unsigned)(bb * a.vt_heads * a.vt_dhead * a.vt_ld + tok);
-    }
-    return r;
-  }
-
-  // Epilogue operands of one (row, 4-column) fragment.  They are FETCHED for a whole batch of
-  // fragments before the first store of the batch: with load -> convert -> store per fragment the
-  // stores (which may alias the residual as far as the compiler knows) serialise the loads, and a
-  // 7-fragment epilogue costs seven dependent L2/fabric round trips (measured 2.2-3.5 us of a
-  // 5-16 us launch with in-kernel s_memtime stamps).
-  struct In {
-    f32x4 rv;
-    f16x4 res;
-  };
-  static __device__ __forceinline__ f32x4 bias4(const IgemmArgs& a, int n) {
-    return (a.bias && n < a.npad) ? *(const f32x4*)(a.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-  static __device__ __forceinline__ int out_col(const IgemmArgs& a, int n) {
-    return (a.flags & UPK_F_GEGLU) ? (n >> 6) * 32 + (n & 31) : n;
-  }
-  static __device__ __forceinline__ In fetch(const IgemmArgs& a, const RowCtx& r, int n) {
-    In in;
-    in.rv = (f32x4){0.f, 0.f, 0.f, 0.f};
-    in.res = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-    if (!r.ok || n >= a.npad) return in;
-    const int oc = out_col(a, n);
-    const bool to_vt = a.vt && n >= a.vt_from;
-    if (oc >= a.n_out && !to_vt) return in;
-    if (a.rowvec) in.rv = *(const f32x4*)(a.rowvec + r.rv_off + n);
-    if (a.res && !to_vt) in.res = *(const f16x4*)(a.res + r.res_off + oc);
-    return in;
-  }
-
-  // finishes and stores packed columns [n, n+4) of the row; v = value accumulators, g = gate
-  // (GEGLU) with their biases bv / bg, `in` = the operands fetched above
-  static __device__ __forceinline__ void store(const IgemmArgs& a, const RowCtx& r, int n, f32x4 v, f32x4 g,
-                                               const f32x4 bv, const f32x4 bg, const In& in) {
-    if (!r.ok) return;
-    const int flags = a.flags;
-    v += bv;
-    if (flags & UPK_F_GEGLU) {
-      // packed rows: [32 value | 32 gate] per 64-row block
-      g += bg;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = v[k] * upk_gelu(g[k]);
-    }
-    const int oc = out_col(a, n);  // output column
-    const bool to_vt = a.vt && n >= a.vt_from;
-    if (oc >= a.n_out && !to_vt) return;
-    if (a.rowvec) v += in.rv;
-    if (flags & UPK_F_SILU) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = upk_silu(v[k]);
-    }
-    if (flags & UPK_F_QUICKGELU) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = v[k] / (1.0f + __expf(-1.702f * v[k]));
-    }
-    if (to_vt) {
-      const int cc = n - a.vt_from;  // = h * dhead + d  ->  row (h*dhead + d) of this sample's V^T
-      f16* dst = a.vt + r.vt_off + (unsigned)cc * (unsigned)a.vt_ld;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) dst[(unsigned)k * (unsigned)a.vt_ld] = (f16)v[k];
-      return;
-    }
-    if (a.res) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] += (float)in.res[k];
-    }
-    if (flags & UPK_F_OUT_NCHW_F32) {
-      float* yo = (float*)a.y + r.nchw_off;
-      const unsigned hw = (unsigned)(a.Ho * a.Wo);
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (oc + k < a.n_out) yo[(unsigned)(oc + k) * hw] = v[k];
-    } else if (flags & UPK_F_OUT_F32) {
-      float* yo = (float*)a.y + r.y_off + oc;
-      if (oc + 3 < a.n_out) {
-        *(f32x4*)yo = v;
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (oc + k < a.n_out) yo[k] = v[k];
-      }
-    } else {
-      f16* yo = (f16*)a.y + r.y_off + oc;
-      if (oc + 3 < a.n_out) {
-        f16x4 o;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = (f16)v[k];
-        *(f16x4*)yo = o;
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (oc + k < a.n_out) yo[k] = (f16)v[k];
-      }
-    }
-  }
-
-  // The common epilogues as STRAIGHT-LINE code.  Every launch starts with a cold instruction cache,
-  // and the general `store` above is a chain of taken branches over the GEGLU / SiLU / V^T / NCHW
-  // blocks: ~8 jumps to cold lines per fragment, 5-8k cycles for a 4..7-fragment tile (s_memtime
-  // stamps, scripts/timeline.py) against ~1k for the stores themselves.
-  //   plain: fp32 acc + bias + timestep row vector + residual -> fp16 NHWC; absent operands point at
-  //          the zero page instead of being branched around;
-  //   geglu: (acc_v + b_v) * gelu(acc_g + b_g) -> fp16.
-  static __host__ __device__ __forceinline__ bool plain(const IgemmArgs& a) {
-    return !(a.flags & (UPK_F_GEGLU | UPK_F_SILU | UPK_F_QUICKGELU | UPK_F_OUT_F32 | UPK_F_OUT_NCHW_F32)) && !a.vt &&
-           !(a.n_out & 3);
-  }
-  static __device__ __forceinline__ bool plain_geglu(const IgemmArgs& a) {
-    return (a.flags & (UPK_F_GEGLU | UPK_F_SILU | UPK_F_QUICKGELU | UPK_F_OUT_F32 | UPK_F_OUT_NCHW_F32)) == UPK_F_GEGLU &&
-           !a.vt &&
-           !a.rowvec && !a.res && !(a.n_out & 3);
-  }
-  struct Plain {
-    const float* bias;
-    const float* rvp;
-    const f16* resp;
-    unsigned has_b, has_rv, has_res;
-    int st, hw;
-    __device__ __forceinline__ Plain(const IgemmArgs& a) {
-      bias = a.bias ? a.bias : (const float*)a.zero;
-      rvp = a.rowvec ? a.rowvec : (const float*)a.zero;
-      resp = a.res ? a.res : a.zero;
-      has_b = a.bias ? ~0u : 0u;
-      has_rv = a.rowvec ? ~0u : 0u;
-      has_res = a.res ? ~0u : 0u;
-      st = (a.rowvec && a.step) ? *a.step : 0;
-      hw = a.Ho * a.Wo;
-    }
-    __device__ __forceinline__ f32x4 bias4(const IgemmArgs& a, int n) const {
-      return *(const f32x4*)(bias + ((n < a.npad ? (unsigned)n : 0u) & has_b));
-    }
-    // row part: offsets of row m (clamped to a valid row; the store is predicated on m < M)
-    struct Row {
-      bool ok;
-      unsigned rv_off, res_off, y_off;
-    };
-    __device__ __forceinline__ Row row(const IgemmArgs& a, int m) const {
-      Row r;
-      r.ok = m < a.M;
-      const unsigned mm = r.ok ? (unsigned)m : 0u;
-      r.rv_off = has_rv ? (unsigned)(st * a.rv_ss + (int)(mm / (unsigned)hw) * a.rv_bs) : 0u;
-      r.res_off = (mm * (unsigned)a.ldr) & has_res;
-      r.y_off = mm * (unsigned)a.ldy;
-      return r;
-    }
-    __device__ __forceinline__ f32x4 rv4(const IgemmArgs& a, const Row& r, int n) const {
-      return *(const f32x4*)(rvp + ((r.rv_off + (n < a.n_out ? (unsigned)n : 0u)) & has_rv));
-    }
-    __device__ __forceinline__ f16x4 res4(const IgemmArgs& a, const Row& r, int n) const {
-      return *(const f16x4*)(resp + r.res_off + ((n < a.n_out ? (unsigned)n : 0u) & has_res));
-    }
-    static __device__ __forceinline__ f16x4 put(const IgemmArgs& a, const Row& r, int n, f32x4 v, const f16x4 rr) {
-      f16x4 o;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) o[k] = (f16)(v[k] + (float)rr[k]);
-      if (r.ok && n < a.n_out) *(f16x4*)((f16*)a.y + r.y_off + n) = o;
-      return o;
-    }
-  };
-
-  // sum over the 16 lanes of a DPP row (= the 16 rows a fragment's lanes with equal lg hold): rotate-add, every
-  // lane ends with the total
-  static __device__ __forceinline__ float row_sum16(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
-    return v;
-  }
-
-  // tile_plain_cp: the tile also leaves the GroupNorm partial sums of what it stores: per (M tile, channel)
-  // sum / sum of squares of the fp16-rounded outputs — in-lane over the MI row fragments, rotate-add over
-  // the 16 rows of a fragment, through `red` (LDS, >= WM*WN*NI*32 floats) over the WM waves of a column, one
-  // fixed order -> bitwise reproducible.  The host guarantees an M tile lies inside one sample (BM | H*W).
-  template <int MI, int NI>
-  static __device__ __forceinline__ void tile_plain(const IgemmArgs& a, int mw, int nw, int lc, int lg,
-                                                    const f32x4 (&acc)[MI][NI]) {
-    const Plain P(a);
-    f32x4 bv[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) bv[j] = P.bias4(a, nw + j * 16 + lg * 4);
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const Plain::Row r = P.row(a, mw + i * 16 + lc);
-      f32x4 rv[NI];
-      f16x4 rr[NI];
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        rv[j] = P.rv4(a, r, nw + j * 16 + lg * 4);
-        rr[j] = P.res4(a, r, nw + j * 16 + lg * 4);
-      }
-#pragma unroll
-      for (int j = 0; j < NI; ++j) Plain::put(a, r, nw + j * 16 + lg * 4, acc[i][j] + bv[j] + rv[j], rr[j]);
-    }
-  }
-
-  // (separate from tile_plain: the extra accumulators and the workgroup barrier must not weigh on every launch)
-  template <int MI, int NI, int WM, int WN>
-  static __device__ __forceinline__ void tile_plain_cp(const IgemmArgs& a, int m0, int mw, int nw, int lc, int lg,
-                                                       const f32x4 (&acc)[MI][NI], int wm, int wn, float* red) {
-    const Plain P(a);
-    constexpr bool cp = true;
-    f32x4 bv[NI];
-    f32x4 cs[NI], cq[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      bv[j] = P.bias4(a, nw + j * 16 + lg * 4);
-      cs[j] = cq[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const Plain::Row r = P.row(a, mw + i * 16 + lc);
-      f32x4 rv[NI];
-      f16x4 rr[NI];
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        rv[j] = P.rv4(a, r, nw + j * 16 + lg * 4);
-        rr[j] = P.res4(a, r, nw + j * 16 + lg * 4);
-      }
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const f16x4 o = Plain::put(a, r, nw + j * 16 + lg * 4, acc[i][j] + bv[j] + rv[j], rr[j]);
-        if (cp) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float f = (float)o[k];
-            cs[j][k] += f;
-            cq[j][k] += f * f;
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        cs[j][k] = row_sum16(cs[j][k]);
-        cq[j][k] = row_sum16(cq[j][k]);
-      }
-    // red[(wm * WN + wn)][j][which][lg * 4 + k]
-    float* mine = red + ((wm * WN + wn) * NI) * 32 + lg * 4;
-    if (lc == 0) {
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        *(f32x4*)(mine + j * 32) = cs[j];
-        *(f32x4*)(mine + j * 32 + 16) = cq[j];
-      }
-    }
-    __syncthreads();
-    if (wm == 0 && lc == 0) {
-      const int b = m0 / a.gn_hw;
-      const int blk = (m0 - b * a.gn_hw) / (MI * 16 * WM);
-      float* dst = a.gn_cp + (long)((b * a.gn_nblk + blk) * 2) * a.npad;
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int n = nw + j * 16 + lg * 4;
-        if (n >= a.npad) continue;
-        f32x4 su = {0.f, 0.f, 0.f, 0.f}, sq = su;
-#pragma unroll
-        for (int w = 0; w < WM; ++w) {
-          su += *(const f32x4*)(red + ((w * WN + wn) * NI + j) * 32 + lg * 4);
-          sq += *(const f32x4*)(red + ((w * WN + wn) * NI + j) * 32 + 16 + lg * 4);
-        }
-        *(f32x4*)(dst + n) = su;
-        *(f32x4*)(dst + a.npad + n) = sq;
-      }
-    }
-  }
-
-  template <int MI, int NI>
-  static __device__ __forceinline__ void tile_geglu(const IgemmArgs& a, int mw, int nw, int lc, int lg,
-                                                    const f32x4 (&acc)[MI][NI]) {
-    static_assert(NI % 4 == 0, "GEGLU tiles are [32 value | 32 gate] column blocks");
-    const float* bias = a.bias ? a.bias : (const float*)a.zero;
-    const unsigned has_b = a.bias ? ~0u : 0u;
-    f32x4 bv[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int n = nw + j * 16 + lg * 4;
-      bv[j] = *(const f32x4*)(bias + ((n < a.npad ? (unsigned)n : 0u) & has_b));
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int m = mw + i * 16 + lc;
-      const bool ok = m < a.M;
-      f16* yrow = (f16*)a.y + (ok ? (unsigned)m : 0u) * (unsigned)a.ldy;
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        if (j & 2) continue;  // gate fragments are consumed by their value partner j - 2
-        const int n = nw + j * 16 + lg * 4;
-        const int oc = (n >> 6) * 32 + (n & 31);
-        const f32x4 v = acc[i][j] + bv[j];
-        const f32x4 g = acc[i][j + 2 < NI ? j + 2 : j] + bv[j + 2 < NI ? j + 2 : j];
-        f16x4 o;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = (f16)(v[k] * upk_gelu(g[k]));
-        if (ok && n < a.npad && oc < a.n_out) *(f16x4*)(yrow + oc) = o;
-      }
-    }
-  }
-
-  // Epilogue of a wave's MI x NI register tile at (mw, nw).
-  template <int MI, int NI, int WM, int WN>
-  static __device__ __forceinline__ void tile(const IgemmArgs& a, int m0, int mw, int nw, int lc, int lg,
-                                              const f32x4 (&acc)[MI][NI], int wm, int wn, float* red) {
-    if (plain(a)) {
-      if (a.gn_cp) tile_plain_cp<MI, NI, WM, WN>(a, m0, mw, nw, lc, lg, acc, wm, wn, red);
-      else tile_plain<MI, NI>(a, mw, nw, lc, lg, acc);
-      return;
-    }
-    if constexpr (NI % 4 == 0) {
-      if (plain_geglu(a)) {
-        tile_geglu<MI, NI>(a, mw, nw, lc, lg, acc);
-        return;
-      }
-    }
-    const bool geglu = a.flags & UPK_F_GEGLU;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const RowCtx rc = row(a, mw + i * 16 + lc);
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int n = nw + j * 16 + lg * 4;
-        if (n >= a.npad) continue;
-        if (geglu) {
-          if constexpr (NI % 4 == 0) {
-            if ((j & 2) == 0) store(a, rc, n, acc[i][j], acc[i][j + 2 < NI ? j + 2 : j], bias4(a, n), bias4(a, n + 32),
-                                    fetch(a, rc, n));
-          }
-        } else {
-          const f32x4 b = bias4(a, n);
-          store(a, rc, n, acc[i][j], acc[i][j], b, b, fetch(a, rc, n));
-        }
-      }
-    }
-  }
-};
 
 // KS = K-chunks (of 32) staged per barrier.  UNet launches have only 1-4 workgroups per CU,
 // so latency must be hidden INSIDE a workgroup: KS chunks of global loads are in flight
@@ -686,7 +249,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
     }
     return;
   }
-  Epi::tile<MI, NI, WM, WN>(a, m0, mw, nw, lc, lg, acc, wm, wn, (float*)smem);
+  Epi::tile<MI, NI, WM, WN>(a, m0, mw, nw, lc, lg, acc, wm, wn, (float*)smem, a.M);
 }
 
 
@@ -1023,7 +586,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
         const int f = wave + 4 * q;
         const int i = f / NI, j = f - i * NI;
         const int n = n0 + j * 16 + lg * 4;
-        rows[q] = P.row(a, f < NF ? m0 + i * 16 + lc : a.M);
+        rows[q] = P.row(a, f < NF ? m0 + i * 16 + lc : a.M, a.M);
         bvs[q] = P.bias4(a, n);
         rvs[q] = P.rv4(a, rows[q], n);
         rrs[q] = P.res4(a, rows[q], n);
@@ -1080,7 +643,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
       const int i = f / NI, j = f - i * NI;
       const int n = n0 + j * 16 + lg * 4;
       const bool live = f < NF && !(geglu && (j & 2));
-      rcs[q] = Epi::row(a, live ? m0 + i * 16 + lc : a.M);
+      rcs[q] = Epi::row(a, live ? m0 + i * 16 + lc : a.M, a.M);
       bvs[q] = Epi::bias4(a, live ? n : a.npad);
       bgs[q] = Epi::bias4(a, live && geglu ? n + 32 : a.npad);
       ins[q] = Epi::fetch(a, rcs[q], n);
@@ -1148,7 +711,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
     }
     return;
   }
-  Epi::tile<MI, NI, WM, WN>(a, m0, mw, nw, lc, lg, acc, wm, wn, (float*)smem);
+  Epi::tile<MI, NI, WM, WN>(a, m0, mw, nw, lc, lg, acc, wm, wn, (float*)smem, a.M);
 #ifdef UPK_TIMELINE
   if (wave == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1180,7 +743,7 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmArgs a, in
   }
   IgemmArgs b = a;
   b.partial = nullptr;
-  const RowCtx rc = Epi::row(b, m);
+  const RowCtx rc = Epi::row(b, m, b.M);
   Epi::store(b, rc, n, v, g, Epi::bias4(b, n), Epi::bias4(b, (a.flags & UPK_F_GEGLU) ? n + 32 : a.npad),
              Epi::fetch(b, rc, n));
 }
@@ -1388,7 +951,7 @@ extern "C" int upk_conv_override(upk_ctx* ctx, int cfg, int splitk) {
 // launch == false: stops after the (config, split-K) decision and reports whether the reduce pass will
 // produce GroupNorm partials (upk_conv_gn_fused)
 static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, bool launch, int* gn_fused,
-                     int* gn_nblk = nullptr) {
+                     int* gn_nblk = nullptr, bool* on_patch = nullptr) {
   if (!ctx || !d) return UPK_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   if (!d->x1 || !d->w_packed || !d->y) return upk_fail(ctx, UPK_EINVAL, "conv: null x1/w/y");
@@ -1481,6 +1044,16 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   a.flags = flags;
   if (const char* ab = getenv("UPK_ABLATE")) a.flags |= (int)strtol(ab, nullptr, 0) & 0x3F0000;
   a.dbg = (unsigned long long*)((char*)ctx->ws + ctx->ws_bytes - 4096);
+
+  if (d->pc_enable) {  // A-stationary patch kernel (pconv.hip)
+    bool handled = false;
+    const int rc = pconv_run(ctx, d, a, stream, launch, gn_fused, gn_nblk, &handled);
+    if (on_patch) *on_patch = handled;
+    if (rc != UPK_OK || handled) return rc;
+  }
+  if (d->gni_mode)
+    return upk_fail(ctx, UPK_ESHAPE, "conv: GroupNorm folded into the input needs the patch kernel (pc_enable, stride 1, "
+                    "no upsample / transposed-V tail / folded LayerNorm)");
 
   // ---- choose config + split-K ----
   int best = -1, best_sk = 1;
@@ -1577,6 +1150,22 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
 
 extern "C" int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream) {
   return conv_impl(ctx, d, stream, true, nullptr);
+}
+
+extern "C" int upk_pconv_supported(upk_ctx* ctx, const upk_conv_desc* d) {
+  if (!ctx || !d || !d->pc_enable) return 0;
+  upk_conv_desc dd = *d;
+  if (dd.gni_mode) {  // the statistics may not be known yet: only the geometry is probed (tiles inside one sample)
+    static const float dummy = 0.f;
+    dd.gni_mode = 1;
+    dd.gni_gamma = dd.gni_beta = dd.gni_stats1 = &dummy;
+    dd.gni_nblk1 = 1;
+    if (dd.gni_groups <= 0) dd.gni_groups = 32;
+  }
+  bool on_patch = false;
+  const int rc = conv_impl(ctx, &dd, nullptr, false, nullptr, nullptr, &on_patch);
+  ctx->err[0] = 0;
+  return rc == UPK_OK && on_patch ? 1 : 0;
 }
 
 extern "C" int upk_conv_gn_fused(upk_ctx* ctx, const upk_conv_desc* d, int* mode, int* nblk) {

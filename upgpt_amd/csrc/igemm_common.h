@@ -1,0 +1,468 @@
+// Shared by igemm.hip and pconv.hip: launch arguments, LDS swizzle and the epilogues of the implicit-GEMM kernels.
+#pragma once
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace upkd {
+
+// debug-only ablation bits (env UPK_ABLATE, read per launch): which phase owns the time?
+enum {
+  ABL_NOEPI = 0x10000,
+  ABL_NOGLOAD = 0x20000,
+  ABL_NOLDSW = 0x40000,
+  ABL_NOMFMA = 0x80000,
+  ABL_EMPTY = 0x100000,  // WS kernel returns at entry (pure launch cost of its geometry)
+  ABL_TIMELINE = 0x200000,  // WS kernel: blocks 0 and gridDim.x-1 write s_memtime stamps to the workspace
+};
+// The ablation / timeline hooks are compiled in only for dev builds (UPK_CXXFLAGS=-DUPK_DEV, scripts/ablate.sh,
+// scripts/timeline*.py): even as never-taken runtime tests they cost scalar registers and instructions in the loops.
+#if defined(UPK_DEV) || defined(UPK_TIMELINE)
+#define ABL_ON(f) ((a.flags & (f)) != 0)
+#else
+#define ABL_ON(f) (false)
+#endif
+
+
+struct IgemmArgs {
+  const f16* x1;
+  const f16* x2;
+  int c1, c2, ld1, ld2;
+  const f16* w;
+  const f16* zero;  // zero page (device)
+  int npad;
+  const float* bias;
+  const f16* res;
+  int ldr;
+  const float* rowvec;
+  int rv_bs, rv_ss;
+  const int* step;
+  void* y;
+  int ldy;
+  f16* vt;
+  int vt_from, vt_heads, vt_dhead, vt_ld, vt_tokens;
+  float* partial;  // split-K slabs [splitk][M][npad] fp32, or nullptr
+  int M, n_out;
+  int B, HS, WS;   // stored input dims
+  int HL, WL;      // logical input dims (after optional 2x upsample)
+  int Ho, Wo;
+  int ks, stride, pad_lo, ups;
+  int linear;      // ks == 1 && stride == 1 && !ups: rows are addressed directly
+  unsigned long long* dbg;  // ABL_TIMELINE stamps
+  const float* ln_u;  // folded LayerNorm: column sums of the packed (gamma-scaled) weight, or nullptr
+  float* gn_cp;       // plain epilogue also writes per-(row block, channel) GroupNorm partials here, or nullptr
+  int gn_nblk, gn_hw;  // row blocks (= M tiles) per sample, pixels per sample
+  float ln_eps;
+  float ln_inv_dim;
+  int cpt;         // 32-wide chunks per tap = (c1+c2)/32
+  int nchunks;     // ks*ks*cpt + appended chunks
+  int nchunks_main;  // ks*ks*cpt: the appended 1x1 segment (x3 | x4 at the output pixel) starts here
+  const f16* x3;
+  const f16* x4;
+  int c3, c4, ld3, ld4;
+  int chunks_per_split;
+  int tiles_m, tiles_n;
+  int flags;
+  // ---- A-stationary patch kernel (pconv.hip): the input patch of an M tile (+ 3x3 halo) is staged ONCE in LDS,
+  // through registers, with the producer GroupNorm(+SiLU) applied on the way
+  int tile_rows;   // valid output rows per M tile (<= BM; tiles never straddle a sample); 0: BM (igemm kernels)
+  int p_pw;        // patch width in pixels (>= Wo + 2*pad; chosen for conflict-free fragment reads)
+  int p_np;        // patch pixels staged per slab
+  int p_ps;        // bytes per patch pixel (= 2*p_cs + 32: 32 mod 64 keeps ds_read_b128 of 16 consecutive pixels conflict free)
+  int p_cs;        // channels per slab (multiple of 32)
+  int p_tpp_log2;  // log2(threads per patch pixel) in the staging pass
+  int gni_mode;    // GroupNorm on the INPUT: 0 none, 1 per-(chunk, group) partials, 2 per-(row block, channel) partials
+  int gni_silu, gni_groups, gni_cpg;
+  float gni_eps;
+  const float* gni_gamma;
+  const float* gni_beta;
+  const float* gni_s1;  // mode 1: [B][nblk1][groups][2]; mode 2: [B][nblk1][2][ld1] of source 1
+  const float* gni_s2;  // mode 2: partials of the second (concat) source
+  int gni_nblk1, gni_ld1, gni_nblk2, gni_ld2;
+};
+
+// 16-byte chunk swizzle for a [rows][4 chunks] fp16 tile (64 B rows).
+// ds_read_b128 is serviced in four 16-lane groups {0-3,12-15,20-27},{4-11,16-19,28-31},...
+// With fragment lane l reading row (l&15), chunk (l>>4), XOR-ing the chunk with
+// (-(row>>2))&3 puts the 16 lanes of every group on 16 distinct 16-B slots of the
+// 256-B bank row.
+__device__ __forceinline__ int lds_swz(int row, int chunk) { return chunk ^ ((-(row >> 2)) & 3); }
+
+// Epilogue, split in a per-ROW part (integer division for the sample index, row offsets:
+// once per 16-row fragment) and a per-4-COLUMN part, with 32-bit offsets against uniform
+// base pointers — with K loops as short as 7..16 chunks the epilogue is a large share of
+// the issued instructions, so it is kept lean.
+struct RowCtx {
+  bool ok;
+  unsigned y_off, res_off, rv_off, vt_off, nchw_off;
+};
+
+struct Epi {
+  static __device__ __forceinline__ RowCtx row(const IgemmArgs& a, int m, int mlim) {
+    RowCtx r;
+    r.ok = m < mlim;
+    const int mm = r.ok ? m : 0;
+    r.y_off = (unsigned)mm * (unsigned)a.ldy;
+    r.res_off = (unsigned)mm * (unsigned)a.ldr;
+    r.rv_off = 0;
+    r.vt_off = 0;
+    r.nchw_off = 0;
+    if (a.rowvec || (a.flags & UPK_F_OUT_NCHW_F32)) {
+      const int hw = a.Ho * a.Wo;
+      const int b = mm / hw;
+      const int p = mm - b * hw;
+      const int st = (a.rowvec && a.step) ? *a.step : 0;
+      r.rv_off = (unsigned)(st * a.rv_ss + b * a.rv_bs);
+      r.nchw_off = (unsigned)(b * a.n_out * hw + p);
+    }
+    if (a.vt) {
+      const int bb = mm / a.vt_tokens;
+      const int tok = mm - bb * a.vt_tokens;
+      r.vt_off = (unsigned)(bb * a.vt_heads * a.vt_dhead * a.vt_ld + tok);
+    }
+    return r;
+  }
+
+  // Epilogue operands of one (row, 4-column) fragment.  They are FETCHED for a whole batch of
+  // fragments before the first store of the batch: with load -> convert -> store per fragment the
+  // stores (which may alias the residual as far as the compiler knows) serialise the loads, and a
+  // 7-fragment epilogue costs seven dependent L2/fabric round trips (measured 2.2-3.5 us of a
+  // 5-16 us launch with in-kernel s_memtime stamps).
+  struct In {
+    f32x4 rv;
+    f16x4 res;
+  };
+  static __device__ __forceinline__ f32x4 bias4(const IgemmArgs& a, int n) {
+    return (a.bias && n < a.npad) ? *(const f32x4*)(a.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  static __device__ __forceinline__ int out_col(const IgemmArgs& a, int n) {
+    return (a.flags & UPK_F_GEGLU) ? (n >> 6) * 32 + (n & 31) : n;
+  }
+  static __device__ __forceinline__ In fetch(const IgemmArgs& a, const RowCtx& r, int n) {
+    In in;
+    in.rv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    in.res = (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+    if (!r.ok || n >= a.npad) return in;
+    const int oc = out_col(a, n);
+    const bool to_vt = a.vt && n >= a.vt_from;
+    if (oc >= a.n_out && !to_vt) return in;
+    if (a.rowvec) in.rv = *(const f32x4*)(a.rowvec + r.rv_off + n);
+    if (a.res && !to_vt) in.res = *(const f16x4*)(a.res + r.res_off + oc);
+    return in;
+  }
+
+  // finishes and stores packed columns [n, n+4) of the row; v = value accumulators, g = gate
+  // (GEGLU) with their biases bv / bg, `in` = the operands fetched above
+  static __device__ __forceinline__ void store(const IgemmArgs& a, const RowCtx& r, int n, f32x4 v, f32x4 g,
+                                               const f32x4 bv, const f32x4 bg, const In& in) {
+    if (!r.ok) return;
+    const int flags = a.flags;
+    v += bv;
+    if (flags & UPK_F_GEGLU) {
+      // packed rows: [32 value | 32 gate] per 64-row block
+      g += bg;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = v[k] * upk_gelu(g[k]);
+    }
+    const int oc = out_col(a, n);  // output column
+    const bool to_vt = a.vt && n >= a.vt_from;
+    if (oc >= a.n_out && !to_vt) return;
+    if (a.rowvec) v += in.rv;
+    if (flags & UPK_F_SILU) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = upk_silu(v[k]);
+    }
+    if (flags & UPK_F_QUICKGELU) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = v[k] / (1.0f + __expf(-1.702f * v[k]));
+    }
+    if (to_vt) {
+      const int cc = n - a.vt_from;  // = h * dhead + d  ->  row (h*dhead + d) of this sample's V^T
+      f16* dst = a.vt + r.vt_off + (unsigned)cc * (unsigned)a.vt_ld;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dst[(unsigned)k * (unsigned)a.vt_ld] = (f16)v[k];
+      return;
+    }
+    if (a.res) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] += (float)in.res[k];
+    }
+    if (flags & UPK_F_OUT_NCHW_F32) {
+      float* yo = (float*)a.y + r.nchw_off;
+      const unsigned hw = (unsigned)(a.Ho * a.Wo);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (oc + k < a.n_out) yo[(unsigned)(oc + k) * hw] = v[k];
+    } else if (flags & UPK_F_OUT_F32) {
+      float* yo = (float*)a.y + r.y_off + oc;
+      if (oc + 3 < a.n_out) {
+        *(f32x4*)yo = v;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (oc + k < a.n_out) yo[k] = v[k];
+      }
+    } else {
+      f16* yo = (f16*)a.y + r.y_off + oc;
+      if (oc + 3 < a.n_out) {
+        f16x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (f16)v[k];
+        *(f16x4*)yo = o;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (oc + k < a.n_out) yo[k] = (f16)v[k];
+      }
+    }
+  }
+
+  // The common epilogues as STRAIGHT-LINE code.  Every launch starts with a cold instruction cache,
+  // and the general `store` above is a chain of taken branches over the GEGLU / SiLU / V^T / NCHW
+  // blocks: ~8 jumps to cold lines per fragment, 5-8k cycles for a 4..7-fragment tile (s_memtime
+  // stamps, scripts/timeline.py) against ~1k for the stores themselves.
+  //   plain: fp32 acc + bias + timestep row vector + residual -> fp16 NHWC; absent operands point at
+  //          the zero page instead of being branched around;
+  //   geglu: (acc_v + b_v) * gelu(acc_g + b_g) -> fp16.
+  static __host__ __device__ __forceinline__ bool plain(const IgemmArgs& a) {
+    return !(a.flags & (UPK_F_GEGLU | UPK_F_SILU | UPK_F_QUICKGELU | UPK_F_OUT_F32 | UPK_F_OUT_NCHW_F32)) && !a.vt &&
+           !(a.n_out & 3);
+  }
+  static __device__ __forceinline__ bool plain_geglu(const IgemmArgs& a) {
+    return (a.flags & (UPK_F_GEGLU | UPK_F_SILU | UPK_F_QUICKGELU | UPK_F_OUT_F32 | UPK_F_OUT_NCHW_F32)) == UPK_F_GEGLU &&
+           !a.vt &&
+           !a.rowvec && !a.res && !(a.n_out & 3);
+  }
+  struct Plain {
+    const float* bias;
+    const float* rvp;
+    const f16* resp;
+    unsigned has_b, has_rv, has_res;
+    int st, hw;
+    __device__ __forceinline__ Plain(const IgemmArgs& a) {
+      bias = a.bias ? a.bias : (const float*)a.zero;
+      rvp = a.rowvec ? a.rowvec : (const float*)a.zero;
+      resp = a.res ? a.res : a.zero;
+      has_b = a.bias ? ~0u : 0u;
+      has_rv = a.rowvec ? ~0u : 0u;
+      has_res = a.res ? ~0u : 0u;
+      st = (a.rowvec && a.step) ? *a.step : 0;
+      hw = a.Ho * a.Wo;
+    }
+    __device__ __forceinline__ f32x4 bias4(const IgemmArgs& a, int n) const {
+      return *(const f32x4*)(bias + ((n < a.npad ? (unsigned)n : 0u) & has_b));
+    }
+    // row part: offsets of row m (clamped to a valid row; the store is predicated on m < M)
+    struct Row {
+      bool ok;
+      unsigned rv_off, res_off, y_off;
+    };
+    __device__ __forceinline__ Row row(const IgemmArgs& a, int m, int mlim) const {
+      Row r;
+      r.ok = m < mlim;
+      const unsigned mm = r.ok ? (unsigned)m : 0u;
+      r.rv_off = has_rv ? (unsigned)(st * a.rv_ss + (int)(mm / (unsigned)hw) * a.rv_bs) : 0u;
+      r.res_off = (mm * (unsigned)a.ldr) & has_res;
+      r.y_off = mm * (unsigned)a.ldy;
+      return r;
+    }
+    __device__ __forceinline__ f32x4 rv4(const IgemmArgs& a, const Row& r, int n) const {
+      return *(const f32x4*)(rvp + ((r.rv_off + (n < a.n_out ? (unsigned)n : 0u)) & has_rv));
+    }
+    __device__ __forceinline__ f16x4 res4(const IgemmArgs& a, const Row& r, int n) const {
+      return *(const f16x4*)(resp + r.res_off + ((n < a.n_out ? (unsigned)n : 0u) & has_res));
+    }
+    static __device__ __forceinline__ f16x4 put(const IgemmArgs& a, const Row& r, int n, f32x4 v, const f16x4 rr) {
+      f16x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = (f16)(v[k] + (float)rr[k]);
+      if (r.ok && n < a.n_out) *(f16x4*)((f16*)a.y + r.y_off + n) = o;
+      return o;
+    }
+  };
+
+  // sum over the 16 lanes of a DPP row (= the 16 rows a fragment's lanes with equal lg hold): rotate-add, every
+  // lane ends with the total
+  static __device__ __forceinline__ float row_sum16(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+  }
+
+  // tile_plain_cp: the tile also leaves the GroupNorm partial sums of what it stores: per (M tile, channel)
+  // sum / sum of squares of the fp16-rounded outputs — in-lane over the MI row fragments, rotate-add over
+  // the 16 rows of a fragment, through `red` (LDS, >= WM*WN*NI*32 floats) over the WM waves of a column, one
+  // fixed order -> bitwise reproducible.  The host guarantees an M tile lies inside one sample (BM | H*W).
+  template <int MI, int NI>
+  static __device__ __forceinline__ void tile_plain(const IgemmArgs& a, int mw, int nw, int lc, int lg,
+                                                    const f32x4 (&acc)[MI][NI], int mlim) {
+    const Plain P(a);
+    f32x4 bv[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) bv[j] = P.bias4(a, nw + j * 16 + lg * 4);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const Plain::Row r = P.row(a, mw + i * 16 + lc, mlim);
+      f32x4 rv[NI];
+      f16x4 rr[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        rv[j] = P.rv4(a, r, nw + j * 16 + lg * 4);
+        rr[j] = P.res4(a, r, nw + j * 16 + lg * 4);
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) Plain::put(a, r, nw + j * 16 + lg * 4, acc[i][j] + bv[j] + rv[j], rr[j]);
+    }
+  }
+
+  // (separate from tile_plain: the extra accumulators and the workgroup barrier must not weigh on every launch)
+  template <int MI, int NI, int WM, int WN>
+  static __device__ __forceinline__ void tile_plain_cp(const IgemmArgs& a, int m0, int mw, int nw, int lc, int lg,
+                                                       const f32x4 (&acc)[MI][NI], int wm, int wn, float* red,
+                                                       int mlim) {
+    const Plain P(a);
+    constexpr bool cp = true;
+    f32x4 bv[NI];
+    f32x4 cs[NI], cq[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      bv[j] = P.bias4(a, nw + j * 16 + lg * 4);
+      cs[j] = cq[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const Plain::Row r = P.row(a, mw + i * 16 + lc, mlim);
+      f32x4 rv[NI];
+      f16x4 rr[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        rv[j] = P.rv4(a, r, nw + j * 16 + lg * 4);
+        rr[j] = P.res4(a, r, nw + j * 16 + lg * 4);
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const f16x4 o = Plain::put(a, r, nw + j * 16 + lg * 4, acc[i][j] + bv[j] + rv[j], rr[j]);
+        if (cp) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float f = r.ok ? (float)o[k] : 0.f;  // (rows past the tile's valid range: pconv partial tiles)
+            cs[j][k] += f;
+            cq[j][k] += f * f;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        cs[j][k] = row_sum16(cs[j][k]);
+        cq[j][k] = row_sum16(cq[j][k]);
+      }
+    // red[(wm * WN + wn)][j][which][lg * 4 + k]
+    float* mine = red + ((wm * WN + wn) * NI) * 32 + lg * 4;
+    if (lc == 0) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        *(f32x4*)(mine + j * 32) = cs[j];
+        *(f32x4*)(mine + j * 32 + 16) = cq[j];
+      }
+    }
+    __syncthreads();
+    if (wm == 0 && lc == 0) {
+      const int b = m0 / a.gn_hw;
+      const int blk = (m0 - b * a.gn_hw) / (a.tile_rows > 0 ? a.tile_rows : MI * 16 * WM);
+      float* dst = a.gn_cp + (long)((b * a.gn_nblk + blk) * 2) * a.npad;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = nw + j * 16 + lg * 4;
+        if (n >= a.npad) continue;
+        f32x4 su = {0.f, 0.f, 0.f, 0.f}, sq = su;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          su += *(const f32x4*)(red + ((w * WN + wn) * NI + j) * 32 + lg * 4);
+          sq += *(const f32x4*)(red + ((w * WN + wn) * NI + j) * 32 + 16 + lg * 4);
+        }
+        *(f32x4*)(dst + n) = su;
+        *(f32x4*)(dst + a.npad + n) = sq;
+      }
+    }
+  }
+
+  template <int MI, int NI>
+  static __device__ __forceinline__ void tile_geglu(const IgemmArgs& a, int mw, int nw, int lc, int lg,
+                                                    const f32x4 (&acc)[MI][NI], int mlim) {
+    static_assert(NI % 4 == 0, "GEGLU tiles are [32 value | 32 gate] column blocks");
+    const float* bias = a.bias ? a.bias : (const float*)a.zero;
+    const unsigned has_b = a.bias ? ~0u : 0u;
+    f32x4 bv[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = nw + j * 16 + lg * 4;
+      bv[j] = *(const f32x4*)(bias + ((n < a.npad ? (unsigned)n : 0u) & has_b));
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = mw + i * 16 + lc;
+      const bool ok = m < mlim;
+      f16* yrow = (f16*)a.y + (ok ? (unsigned)m : 0u) * (unsigned)a.ldy;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        if (j & 2) continue;  // gate fragments are consumed by their value partner j - 2
+        const int n = nw + j * 16 + lg * 4;
+        const int oc = (n >> 6) * 32 + (n & 31);
+        const f32x4 v = acc[i][j] + bv[j];
+        const f32x4 g = acc[i][j + 2 < NI ? j + 2 : j] + bv[j + 2 < NI ? j + 2 : j];
+        f16x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (f16)(v[k] * upk_gelu(g[k]));
+        if (ok && n < a.npad && oc < a.n_out) *(f16x4*)(yrow + oc) = o;
+      }
+    }
+  }
+
+  // Epilogue of a wave's MI x NI register tile at (mw, nw).
+  template <int MI, int NI, int WM, int WN>
+  static __device__ __forceinline__ void tile(const IgemmArgs& a, int m0, int mw, int nw, int lc, int lg,
+                                              const f32x4 (&acc)[MI][NI], int wm, int wn, float* red, int mlim) {
+    if (plain(a)) {
+      if (a.gn_cp) tile_plain_cp<MI, NI, WM, WN>(a, m0, mw, nw, lc, lg, acc, wm, wn, red, mlim);
+      else tile_plain<MI, NI>(a, mw, nw, lc, lg, acc, mlim);
+      return;
+    }
+    if constexpr (NI % 4 == 0) {
+      if (plain_geglu(a)) {
+        tile_geglu<MI, NI>(a, mw, nw, lc, lg, acc, mlim);
+        return;
+      }
+    }
+    const bool geglu = a.flags & UPK_F_GEGLU;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const RowCtx rc = row(a, mw + i * 16 + lc, mlim);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = nw + j * 16 + lg * 4;
+        if (n >= a.npad) continue;
+        if (geglu) {
+          if constexpr (NI % 4 == 0) {
+            if ((j & 2) == 0) store(a, rc, n, acc[i][j], acc[i][j + 2 < NI ? j + 2 : j], bias4(a, n), bias4(a, n + 32),
+                                    fetch(a, rc, n));
+          }
+        } else {
+          const f32x4 b = bias4(a, n);
+          store(a, rc, n, acc[i][j], acc[i][j], b, b, fetch(a, rc, n));
+        }
+      }
+    }
+  }
+};
+
+
+// pconv.hip: runs the launch on the A-stationary patch kernel when the shape is inside its domain
+int pconv_run(upk_ctx* ctx, const upk_conv_desc* d, IgemmArgs& a, hipStream_t stream, bool launch, int* gn_fused,
+              int* gn_nblk, bool* handled);
+
+}  // namespace upkd

@@ -307,14 +307,22 @@ extern "C" size_t upk_groupnorm_ws_bytes(int batch, int hw) {
   return (size_t)batch * nch * GN_GROUPS_MAX * 2 * sizeof(float);
 }
 
+extern "C" int upk_groupnorm_chunks(int hw) {
+  int nch, ppc;
+  upk_gn_chunking(hw, &nch, &ppc);
+  return nch;
+}
+
 static int gn_launch(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* x2, int c2, int ld2, int batch, int hw,
                      int groups, const float* gamma, const float* beta, float eps, int fuse_silu, void* y, int ldy,
                      float* stats_ws, upk_stream stream_, bool with_stats, int cp_nblk = 0, int cp_ld = 0,
-                     const float* stats_ws2 = nullptr, int cp_nblk2 = 0, int cp_ld2 = 0) {
+                     const float* stats_ws2 = nullptr, int cp_nblk2 = 0, int cp_ld2 = 0, bool with_apply = true) {
   if (!ctx) return UPK_EINVAL;
-  if (!x1 || !gamma || !beta || !y || !stats_ws) return upk_fail(ctx, UPK_EINVAL, "groupnorm: null pointer");
+  if (!x1 || !stats_ws || (with_apply && (!gamma || !beta || !y)))
+    return upk_fail(ctx, UPK_EINVAL, "groupnorm: null pointer");
   const int C = c1 + c2;
-  if (c1 <= 0 || c2 < 0 || (c1 & 7) || (c2 & 7) || (c2 && !x2) || (ld1 & 7) || (c2 && (ld2 & 7)) || (ldy & 7))
+  if (c1 <= 0 || c2 < 0 || (c1 & 7) || (c2 & 7) || (c2 && !x2) || (ld1 & 7) || (c2 && (ld2 & 7)) ||
+      (with_apply && (ldy & 7)))
     return upk_fail(ctx, UPK_EINVAL, "groupnorm: channels / leading dims must be multiples of 8");
   if (groups <= 0 || groups > GN_GROUPS_MAX || C % groups || C > 2048)
     return upk_fail(ctx, UPK_ESHAPE, "groupnorm: C=%d groups=%d unsupported", C, groups);
@@ -352,7 +360,7 @@ static int gn_launch(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* 
   if (with_stats) {
     hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nchunks, batch), dim3(256), 0, stream, a);
     rc = upk_check_launch(ctx, "gn_stats");
-    if (rc) return rc;
+    if (rc || !with_apply) return rc;
   }
   // apply: ~4 KB of fp16 per block (>= 3 blocks per CU on the UNet shapes: the kernel is a chain of
   // dependent memory round trips, so it needs co-resident blocks, not long per-block loops)
@@ -369,6 +377,12 @@ extern "C" int upk_groupnorm_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int 
                                       upk_stream stream) {
   return gn_launch(ctx, x1, c1, ld1, x2, c2, ld2, batch, hw, groups, gamma, beta, eps, fuse_silu, y, ldy, stats_ws,
                    stream, true);
+}
+
+extern "C" int upk_groupnorm_stats_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* x2, int c2, int ld2,
+                                            int batch, int hw, int groups, float* stats_ws, upk_stream stream) {
+  return gn_launch(ctx, x1, c1, ld1, x2, c2, ld2, batch, hw, groups, nullptr, nullptr, 0.f, 0, nullptr, 0, stats_ws,
+                   stream, true, 0, 0, nullptr, 0, 0, false);
 }
 
 extern "C" int upk_groupnorm_apply_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* x2, int c2,

@@ -63,6 +63,7 @@ class TuneCache:
 
 
 TUNE_CACHE = TuneCache(os.environ.get("UPGPT_TUNE_FILE") or None)
+PCONV_ON = os.environ.get("UPGPT_PCONV", "1") != "0"  # A-stationary patch kernel (csrc/pconv.hip) for the 3x3 convs
 LN_LAUNCH_US = 3.0  # what a separate LayerNorm launch costs inside the replayed forward (class ablation: 3.8)
 
 
@@ -204,6 +205,7 @@ class Program:
         self.ctx = ctx
         self.ops = []
         self.cls = []
+        self.labels = []
         self.keep = []
         self.igemm_flops = 0
         self.attn_flops = 0
@@ -220,9 +222,10 @@ class Program:
         for op in self.ops:
             op(s)
 
-    def add(self, fn, *keep, cls="other"):
+    def add(self, fn, *keep, cls="other", label=None):
         self.ops.append(fn)
         self.cls.append(cls)
+        self.labels.append(label or cls)
         self.keep.extend(keep)
         self.n_launch += 1
 
@@ -245,6 +248,8 @@ class Emitter:
         cache = TUNE_CACHE if cache is None else cache
         hits = tuned = missing = 0
         for d, key in self.convs:
+            if d.pc_enable:
+                continue  # (patch-kernel launches pick their tile configuration themselves)
             ent = cache.get(key)
             if ent is None and tune_missing:
                 cfg, sk, best_us, dflt_us = self.ctx.conv_autotune(d, reps or int(os.environ.get("UPGPT_TUNE_REPS", "5")))
@@ -281,6 +286,8 @@ class Emitter:
         mode = os.environ.get("UPGPT_SKIP_FOLD", "auto")
         if mode != "auto":
             return mode == "1"
+        if PCONV_ON and pw_main.ksize == 3:
+            return True  # the patch kernel takes the appended segment as one more slab of its K loop
         c3, c4 = _rup(x.C, 32), (_rup(skip.C, 32) if skip is not None else 0)
         base = (hN.M, pw_main.n_pad, _rup(hN.C, 32), 0, pw_main.ksize, 1, 0)
         def tuned(key):  # (a launch whose output feeds a GroupNorm is tuned under its "_gs" name)
@@ -335,11 +342,20 @@ class Emitter:
 
     def conv(self, P, x1, pw, *, x2=None, stride=1, flags=0, residual=None, rowvec=None, rv_bs=0, rv_ss=0,
              step=None, out=None, vt=None, nchw_out=None, out_f32=None, spatial=None, ln_eps=None,
-             gn_stats=False, append=None):
+             gn_stats=False, append=None, gn=None):
         """Emits one upk_conv2d_nhwc_f16. Returns the output Act (fp16) unless nchw_out /
-        out_f32 is given."""
+        out_f32 is given.
+
+        gn = (gamma, beta, eps, silu, ws): x1 | x2 are UN-normalised and the GroupNorm(+SiLU) in front of this conv
+        (openaimodel.py:255-275, attention.py:250-256) is folded into the patch kernel's staging pass
+        (include/upk.h gni_*); shapes outside that kernel's domain get the GroupNorm launch + a plain conv."""
         B, H, W = spatial if spatial is not None else (x1.B, x1.H, x1.W)
         ks = pw.ksize
+        kw_all = dict(stride=stride, flags=flags, residual=residual, rowvec=rowvec, rv_bs=rv_bs, rv_ss=rv_ss, step=step,
+                      out=out, vt=vt, nchw_out=nchw_out, out_f32=out_f32, spatial=spatial, ln_eps=ln_eps,
+                      gn_stats=gn_stats, append=append)
+        if gn is not None and not PCONV_ON:
+            return self.conv(P, self.groupnorm(P, x1, gn[0], gn[1], gn[2], gn[3], gn[4], x2=x2), pw, **kw_all)
         ups = bool(flags & L.F_UPSAMPLE2X)
         HL, WL = (2 * H, 2 * W) if ups else (H, W)
         if flags & L.F_PAD_ASYM:
@@ -373,6 +389,7 @@ class Emitter:
         if step is not None:
             d.step = step.data_ptr()
         ret = None
+        out_mine = False
         if nchw_out is not None:
             d.y = nchw_out.data_ptr()
             d.ldy = 0
@@ -382,6 +399,7 @@ class Emitter:
             d.ldy = out_f32.shape[-1]
             flags |= L.F_OUT_F32
         else:
+            out_mine = out is None
             if out is None:
                 ld = pw.n_out if pw.n_out % 8 == 0 else _rup(pw.n_out, 32)
                 out = Act(self.alloc(M, ld, zero=(ld != pw.n_out)), B, Ho, Wo, pw.n_out)
@@ -414,15 +432,91 @@ class Emitter:
             assert d.c3 + d.c4 == pw.k_append, ("appended K mismatch", d.c3, d.c4, pw.k_append)
         else:
             assert not pw.k_append
-        self.convs.append((d, self.conv_key(M, pw.n_pad, d.c1, d.c2, ks, stride, flags, residual is not None,
-                                            rowvec is not None, vt is not None, ln_eps is not None,
-                                            ka=d.c3 + d.c4)))
+        use_pc = (PCONV_ON and stride == 1 and not ups and not (flags & L.F_PAD_ASYM) and ln_eps is None and vt is None
+                  and (ks == 3 or gn is not None))
+        if use_pc:
+            d.pc_enable = 1
+            d.gni_mode, d.gni_groups = (1, 32) if gn is not None else (0, 0)  # (provisional: fixed when the program runs)
+            if not self.lib.upk_pconv_supported(self.hctx, C.byref(d)):
+                d.pc_enable, d.gni_mode, use_pc = 0, 0, False
+        if gn is not None and not use_pc:  # outside the patch kernel's domain: GroupNorm launch + plain conv
+            if out_mine:
+                self.bufs.pop()  # (the output buffer allocated above is re-made by the plain call)
+            return self.conv(P, self.groupnorm(P, x1, gn[0], gn[1], gn[2], gn[3], gn[4], x2=x2), pw, **kw_all)
+        key = self.conv_key(M, pw.n_pad, d.c1, d.c2, ks, stride, flags, residual is not None, rowvec is not None,
+                            vt is not None, ln_eps is not None, ka=d.c3 + d.c4)
+        if use_pc:
+            key += "_pc" + ("" if gn is None else "_gn%d" % int(bool(gn[3])))
+        self.convs.append((d, key))
         fn, h, ref = self.lib.upk_conv2d_nhwc_f16, self.hctx, C.byref(d)
         chk = self._chk
-        P.add(lambda s: chk(fn(h, ref, s)), d, pw, x1, x2, x3, x4, residual, rowvec, out, nchw_out, out_f32, vt,
-              cls="igemm_k%d" % ks)
+        keep = (d, pw, x1, x2, x3, x4, residual, rowvec, out, nchw_out, out_f32, vt)
+        if gn is None:
+            P.add(lambda s: chk(fn(h, ref, s)), *keep, cls="igemm_k%d" % ks, label=key)
+        else:
+            gamma, beta, eps, silu, ws = gn
+            assert x1.C == d.c1 and (x2 is None or x2.C == d.c2), "fused GroupNorm needs channel counts that are multiples of 32"
+            d.gni_gamma, d.gni_beta, d.gni_eps = gamma.data_ptr(), beta.data_ptr(), float(eps)
+            d.gni_silu, d.gni_groups = int(bool(silu)), 32
+            srcs = [x1] if x2 is None else [x1, x2]
+            armed = self._arm_gn_sources(srcs)
+            hw_in = H * W
+            nch = self.lib.upk_groupnorm_chunks(hw_in)
+            fused_fn, stats_fn = self.lib.upk_conv_gn_fused, self.lib.upk_groupnorm_stats_nhwc_f16
+            sa = (x1.t.data_ptr(), x1.C, x1.ld, x2.t.data_ptr() if x2 is not None else None,
+                  x2.C if x2 is not None else 0, x2.ld if x2 is not None else 0, B, hw_in, 32)
+
+            def run(s):
+                info = []
+                for dsrc, sws in (armed or ()):
+                    mode, nblk = C.c_int(0), C.c_int(0)
+                    chk(fused_fn(h, C.byref(dsrc), C.byref(mode), C.byref(nblk)))
+                    info.append((mode.value, nblk.value, dsrc.n_pad, sws.data_ptr()))
+                if info and all(i[0] == 2 for i in info):
+                    d.gni_mode = 2
+                    d.gni_stats1, d.gni_nblk1, d.gni_ld1 = info[0][3], info[0][1], info[0][2]
+                    if len(info) == 2:
+                        d.gni_stats2, d.gni_nblk2, d.gni_ld2 = info[1][3], info[1][1], info[1][2]
+                elif len(info) == 1 and info[0][0] == 1:
+                    d.gni_mode, d.gni_stats1, d.gni_nblk1 = 1, info[0][3], nch
+                else:  # no usable by-product: statistics pass of the input, then the fused conv
+                    chk(stats_fn(h, *sa, ws.data_ptr(), s))
+                    d.gni_mode, d.gni_stats1, d.gni_nblk1 = 1, ws.data_ptr(), nch
+                chk(fn(h, ref, s))
+
+            P.add(run, *keep, gamma, beta, ws, armed, cls="igemm_k%d" % ks, label=key)
         P.igemm_flops += 2 * M * pw.n_real * pw.k_real
         return ret
+
+    def _arm_gn_sources(self, acts):
+        """Arms the producer launch of every source Act to leave the GroupNorm partial sums of its output
+        (include/upk.h gn_stats_ws).  Returns [(producer ConvDesc, stats buffer)] or None when a source has no such
+        producer / a concat source is known to split K (per-group partials cannot be combined across the seam)."""
+        srcs = [getattr(a, "gn_src", None) for a in acts]
+        if any(sr is None for sr in srcs):
+            return None
+        if len(acts) > 1:
+            if os.environ.get("UPGPT_GN_2SRC", "1") != "1":
+                return None
+            for sr in srcs:
+                if sr[0].pc_enable:
+                    continue  # the patch kernel never splits K
+                key = self.convs[sr[1]][1]
+                e = TUNE_CACHE.get(key) or TUNE_CACHE.get(key[:-3] if key.endswith("_gs") else key + "_gs")
+                if e is None or e[1] != 1:
+                    return None
+        armed = []
+        for act in acts:
+            d = act.gn_src[0]
+            if not d.gn_stats_ws:  # arm the producer and rename its tuning key
+                ci = act.gn_src[1]
+                sws = self.alloc(self.ctx.gn_stats_floats(act.B, d.n_pad), dtype=torch.float32)
+                d.gn_stats_ws, d.gn_groups = sws.data_ptr(), 32
+                assert self.convs[ci][0] is d
+                self.convs[ci] = (d, self.convs[ci][1] + "_gs")
+                act.gn_src = (d, ci, sws)
+            armed.append((d, act.gn_src[2]))
+        return armed
 
     def groupnorm(self, P, x1, gamma, beta, eps, silu, ws, x2=None):
         Cc = x1.C + (x2.C if x2 is not None else 0)
@@ -431,36 +525,15 @@ class Emitter:
         a = (x1.t.data_ptr(), x1.C, x1.ld, x2.t.data_ptr() if x2 is not None else None, x2.C if x2 is not None else 0,
              x2.ld if x2 is not None else 0, x1.B, x1.H * x1.W, 32, gamma.data_ptr(), beta.data_ptr(), float(eps),
              int(bool(silu)), y.t.data_ptr(), y.ld)
-        srcs = [getattr(x1, "gn_src", None)] + ([getattr(x2, "gn_src", None)] if x2 is not None else [])
-        if x2 is not None and os.environ.get("UPGPT_GN_2SRC", "1") != "1":
-            srcs = [None]
-        if x2 is not None and all(sr is not None for sr in srcs):
-            # a concat input is only worth arming when both producers are known to run unsplit (channel partials):
-            # a split-K producer's per-group partials cannot be combined across the seam
-            for sr in srcs:
-                key = self.convs[sr[1]][1]
-                e = TUNE_CACHE.get(key) or TUNE_CACHE.get(key[:-3] if key.endswith("_gs") else key + "_gs")
-                if e is None or e[1] != 1:
-                    srcs = [None]
-                    break
-        if any(sr is None for sr in srcs):
-            P.add(lambda s: chk(fn(h, *a, ws.data_ptr(), s)), x1, x2, gamma, beta, y, ws, cls="groupnorm")
+        armed = self._arm_gn_sources([x1] if x2 is None else [x1, x2])
+        if armed is None:
+            P.add(lambda s: chk(fn(h, *a, ws.data_ptr(), s)), x1, x2, gamma, beta, y, ws, cls="groupnorm",
+                  label="gn M%d C%d silu%d 2pass" % (x1.M, Cc, int(bool(silu))))
         else:
             # the producer conv(s) may have left the partial statistics of the input in their own buffers: per-group
             # partials from a split-K reduce pass (single source only) or per-(M tile, channel) partials from an
             # unsplit epilogue (every source of a concat must have them); decided by the tuned / cost-model choice
             # at the time the program runs or is captured
-            armed = []
-            for act in ([x1] if x2 is None else [x1, x2]):
-                d = act.gn_src[0]
-                if not d.gn_stats_ws:  # arm the producer and rename its tuning key
-                    ci = act.gn_src[1]
-                    sws = self.alloc(self.ctx.gn_stats_floats(act.B, d.n_pad), dtype=torch.float32)
-                    d.gn_stats_ws, d.gn_groups = sws.data_ptr(), 32
-                    assert self.convs[ci][0] is d
-                    self.convs[ci] = (d, self.convs[ci][1] + "_gs")
-                    act.gn_src = (d, ci, sws)
-                armed.append((d, act.gn_src[2]))
             fused_fn, apply_fn = self.lib.upk_conv_gn_fused, self.lib.upk_groupnorm_apply_nhwc_f16
 
             def run(s):
@@ -477,7 +550,8 @@ class Emitter:
                 else:
                     chk(fn(h, *a, ws.data_ptr(), s))
 
-            P.add(run, x1, x2, gamma, beta, y, ws, armed, cls="groupnorm")
+            P.add(run, x1, x2, gamma, beta, y, ws, armed, cls="groupnorm",
+                  label="gn M%d C%d silu%d" % (x1.M, Cc, int(bool(silu))))
         P.n_launch += 1  # stats + apply
         return y
 
@@ -485,14 +559,15 @@ class Emitter:
         y = Act(self.alloc(x.M, x.C), x.B, x.H, x.W, x.C)
         fn, h, chk = self.lib.upk_layernorm_f16, self.hctx, self._chk
         a = (x.t.data_ptr(), x.ld, x.M, x.C, gamma.data_ptr(), beta.data_ptr(), float(eps), y.t.data_ptr(), y.ld)
-        P.add(lambda s: chk(fn(h, *a, s)), x, gamma, beta, y, cls="layernorm")
+        P.add(lambda s: chk(fn(h, *a, s)), x, gamma, beta, y, cls="layernorm", label="ln M%d C%d" % (x.M, x.C))
         return y
 
     def attention(self, P, q, ldq, qbs, k, ldk, kbs, vt, vt_ld, out, ldo, obs, B, heads, nq, nkv, dp, scale):
         fn, h, chk = self.lib.upk_attention_f16, self.hctx, self._chk
         a = (q.data_ptr(), ldq, qbs, k.data_ptr(), ldk, kbs, vt.data_ptr(), vt_ld, out.data_ptr(), ldo, obs, B, heads,
              nq, nkv, dp, float(scale))
-        P.add(lambda s: chk(fn(h, *a, s)), q, k, vt, out, cls="attention")
+        P.add(lambda s: chk(fn(h, *a, s)), q, k, vt, out, cls="attention",
+              label="attn B%d h%d nq%d nkv%d d%d" % (B, heads, nq, nkv, dp))
 
 
 # ====================================================================== UNet
@@ -644,20 +719,19 @@ class UNetPlan(Emitter):
             raise ValueError("UNet skip connection %dx%d does not match the decoder feature map %dx%d at %s: "
                              "latent height and width must be multiples of %d" % (
                                  skip.H, skip.W, x.H, x.W, n, 2 ** (len(self.arch.channel_mult) - 1)))
-        g, b = v[n + ".in_layers.0"]
-        hN = self.groupnorm(P, x, g, b, 1e-5, True, self.gn_ws, x2=skip)
-        hh = self.conv(P, hN, w[n + ".in_layers.2"], gn_stats=True, **self._rv(n))
-        g, b = v[n + ".out_layers.0"]
-        hN = self.groupnorm(P, hh, g, b, 1e-5, True, self.gn_ws)
+        g1, b1 = v[n + ".in_layers.0"]
+        hh = self.conv(P, x, w[n + ".in_layers.2"], x2=skip, gn=(g1, b1, 1e-5, True, self.gn_ws), gn_stats=True,
+                       **self._rv(n))
+        gn2 = (*v[n + ".out_layers.0"], 1e-5, True, self.gn_ws)
         if Lr.cin != Lr.cout:
-            if self.fold_skip(hN, w[n + ".out_layers.3"], w[n + ".skip_connection"], x, skip):
+            if self.fold_skip(hh, w[n + ".out_layers.3"], w[n + ".skip_connection"], x, skip):
                 # skip projection as an appended K segment of the second conv: one launch, no residual round trip
-                return self.conv(P, hN, w[n + ".out_layers.3+skip"], append=(x, skip), gn_stats=True)
+                return self.conv(P, hh, w[n + ".out_layers.3+skip"], append=(x, skip), gn=gn2, gn_stats=True)
             sk = self.conv(P, x, w[n + ".skip_connection"], x2=skip)
         else:
             assert skip is None
             sk = x
-        return self.conv(P, hN, w[n + ".out_layers.3"], residual=sk, gn_stats=True)
+        return self.conv(P, hh, w[n + ".out_layers.3"], residual=sk, gn=gn2, gn_stats=True)
 
     def _st(self, P, Lr, x):
         w, v = self.pk.w, self.pk.v
@@ -668,9 +742,7 @@ class UNetPlan(Emitter):
         dp = head_pad(dh)
         hd = heads * dp
         scale = dh ** -0.5
-        g, b = v[n + ".norm"]
-        xn = self.groupnorm(P, x, g, b, 1e-6, False, self.gn_ws)
-        t0 = self.conv(P, xn, w[n + ".proj_in"])
+        t0 = self.conv(P, x, w[n + ".proj_in"], gn=(*v[n + ".norm"], 1e-6, False, self.gn_ws))
         # self-attention
         qk = Act(self.alloc(M, 2 * hd), B, x.H, x.W, 2 * hd)
         vt_ld = _rup(HW, 32)
@@ -727,9 +799,7 @@ class UNetPlan(Emitter):
         for i, blk in enumerate(a.output_blocks):
             x = self._layers(P, blk, x, skip=hs.pop())
             self.taps["output_blocks.%d" % i] = x
-        g, b = self.pk.v["out.0"]
-        xn = self.groupnorm(P, x, g, b, 1e-5, True, self.gn_ws)
-        self.conv(P, xn, self.pk.w["out.2"], nchw_out=self.eps)
+        self.conv(P, x, self.pk.w["out.2"], nchw_out=self.eps, gn=(*self.pk.v["out.0"], 1e-5, True, self.gn_ws))
 
     # ---- host-facing helpers
     def load_context(self, context):
@@ -807,11 +877,10 @@ class VAEDecodePlan(Emitter):
             if Lr.kind == "conv":
                 x = self.conv(P, x, W_[n])
             elif Lr.kind == "resnet":
-                hN = self.groupnorm(P, x, *V_[n + ".norm1"], 1e-6, True, self.gn_ws)
-                h1 = self.conv(P, hN, W_[n + ".conv1"])
-                hN = self.groupnorm(P, h1, *V_[n + ".norm2"], 1e-6, True, self.gn_ws)
+                h1 = self.conv(P, x, W_[n + ".conv1"], gn=(*V_[n + ".norm1"], 1e-6, True, self.gn_ws), gn_stats=True)
                 sk = self.conv(P, x, W_[n + ".nin_shortcut"]) if Lr.cin != Lr.cout else x
-                x = self.conv(P, hN, W_[n + ".conv2"], residual=sk)
+                x = self.conv(P, h1, W_[n + ".conv2"], residual=sk, gn=(*V_[n + ".norm2"], 1e-6, True, self.gn_ws),
+                              gn_stats=True)
             elif Lr.kind == "attn":
                 c, HW = Lr.ch, x.H * x.W
                 xn = self.groupnorm(P, x, *V_[n + ".norm"], 1e-6, False, self.gn_ws)
@@ -902,11 +971,10 @@ class VAEEncodePlan(Emitter):
             if Lr.kind == "conv":
                 x = self.conv(P, x, W_[n])
             elif Lr.kind == "resnet":
-                hN = self.groupnorm(P, x, *V_[n + ".norm1"], 1e-6, True, self.gn_ws)
-                h1 = self.conv(P, hN, W_[n + ".conv1"])
-                hN = self.groupnorm(P, h1, *V_[n + ".norm2"], 1e-6, True, self.gn_ws)
+                h1 = self.conv(P, x, W_[n + ".conv1"], gn=(*V_[n + ".norm1"], 1e-6, True, self.gn_ws), gn_stats=True)
                 sk = self.conv(P, x, W_[n + ".nin_shortcut"]) if Lr.cin != Lr.cout else x
-                x = self.conv(P, hN, W_[n + ".conv2"], residual=sk)
+                x = self.conv(P, h1, W_[n + ".conv2"], residual=sk, gn=(*V_[n + ".norm2"], 1e-6, True, self.gn_ws),
+                              gn_stats=True)
             elif Lr.kind == "attn":
                 c, HW = Lr.ch, x.H * x.W
                 xn = self.groupnorm(P, x, *V_[n + ".norm"], 1e-6, False, self.gn_ws)
