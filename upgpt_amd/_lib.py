@@ -11,7 +11,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libupk.so")
+LIB_PATH = os.environ.get("UPK_LIB") or os.path.join(_HERE, "libupk.so")  # (UPK_LIB: dev builds)
 
 # every symbol include/upk.h declares (tests check the library exports all of them)
 SYMBOLS = [

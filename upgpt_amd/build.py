@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "libupk.so")
+OUT = os.environ.get("UPK_LIB") or os.path.join(HERE, "libupk.so")  # (UPK_LIB + UPK_CXXFLAGS: dev builds)
 SOURCES = ["igemm.hip", "pconv.hip", "attention.hip", "norm.hip", "misc.hip"]
 ARCH = "gfx950"
 
@@ -37,7 +37,7 @@ def build(force=False, verbose=True):
     if not force and not _stale():
         return OUT
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" + ("_dev" if os.environ.get("UPK_LIB") else ""))
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
              "-Wno-unused-result", "-I", os.path.join(HERE, "..", "include")]

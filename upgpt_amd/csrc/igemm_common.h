@@ -71,6 +71,9 @@ struct IgemmArgs {
   int p_ps;        // bytes per patch pixel (= 2*p_cs + 32: 32 mod 64 keeps ds_read_b128 of 16 consecutive pixels conflict free)
   int p_cs;        // channels per slab (multiple of 32)
   int p_tpp_log2;  // log2(threads per patch pixel) in the staging pass
+  int p_T;         // total number of ring stages
+  int p_xcd;       // XCD-aware tile order (all M tiles of an N tile on one XCD)
+  int p_tab;       // bytes of the GroupNorm scale / shift table in LDS
   int gni_mode;    // GroupNorm on the INPUT: 0 none, 1 per-(chunk, group) partials, 2 per-(row block, channel) partials
   int gni_silu, gni_groups, gni_cpg;
   float gni_eps;

@@ -63,7 +63,11 @@ class TuneCache:
 
 
 TUNE_CACHE = TuneCache(os.environ.get("UPGPT_TUNE_FILE") or None)
-PCONV_ON = os.environ.get("UPGPT_PCONV", "1") != "0"  # A-stationary patch kernel (csrc/pconv.hip) for the 3x3 convs
+# A-stationary patch kernel (csrc/pconv.hip, GroupNorm folded into its staging pass): "0" (default) / "auto" / "all".
+# Off by default: parity-green, but inside the replayed forward it does not beat implicit GEMM + GroupNorm launch yet
+# (profiles/r02_pconv_*): 3.61 ms vs 3.52 ms per forward with the "auto" rule below.
+PCONV_MODE = os.environ.get("UPGPT_PCONV", "0")
+PCONV_ON = PCONV_MODE != "0"
 LN_LAUNCH_US = 3.0  # what a separate LayerNorm launch costs inside the replayed forward (class ablation: 3.8)
 
 
@@ -286,7 +290,7 @@ class Emitter:
         mode = os.environ.get("UPGPT_SKIP_FOLD", "auto")
         if mode != "auto":
             return mode == "1"
-        if PCONV_ON and pw_main.ksize == 3:
+        if PCONV_MODE == "all" and pw_main.ksize == 3:
             return True  # the patch kernel takes the appended segment as one more slab of its K loop
         c3, c4 = _rup(x.C, 32), (_rup(skip.C, 32) if skip is not None else 0)
         base = (hN.M, pw_main.n_pad, _rup(hN.C, 32), 0, pw_main.ksize, 1, 0)
@@ -319,6 +323,21 @@ class Emitter:
         if e_f is None or e_a is None or e_b is None:
             return False
         return e_f[2] < e_a[2] + e_b[2]
+
+    @staticmethod
+    def pconv_pays(M, ks, concat, appended):
+        """Where the patch kernel (GroupNorm folded into its staging pass) beats implicit GEMM + GroupNorm launch on an
+        MI355X (scripts/pc_bench.py vs scripts/op_trace.py, B = 8): the long-M levels with one staging slab —
+        3x3 224->224 @32x32 22.7 vs 28.5 us, (448+224)->224 48.1 vs 59.3, 448->448 @16x16 27.2 vs 32.8, 1x1 proj_in
+        @32x32 12.2 vs 14.3.  The 8x8 / 4x4 levels (weight streaming: 41 vs 33 us, 32 vs 23) and launches with an
+        appended 1x1 segment (36 vs 33) stay on the split-K implicit GEMM.  UPGPT_PCONV=all forces it everywhere."""
+        if PCONV_MODE == "all":
+            return True
+        if appended:
+            return False
+        if ks == 3:
+            return M >= 8192 or (M >= 2048 and not concat)
+        return M >= 8192
 
     def ln_linear(self, P, x, name, norm, flags=0, **kw):
         """LayerNorm `norm` followed by the Linear `name`: either one launch with the norm folded into the
@@ -433,7 +452,7 @@ class Emitter:
         else:
             assert not pw.k_append
         use_pc = (PCONV_ON and stride == 1 and not ups and not (flags & L.F_PAD_ASYM) and ln_eps is None and vt is None
-                  and (ks == 3 or gn is not None))
+                  and (ks == 3 or gn is not None) and self.pconv_pays(M, ks, x2 is not None, append is not None))
         if use_pc:
             d.pc_enable = 1
             d.gni_mode, d.gni_groups = (1, 32) if gn is not None else (0, 0)  # (provisional: fixed when the program runs)
