@@ -341,6 +341,12 @@ int upk_ddim_step_cfg_f32(upk_ctx* ctx, float* x, const float* eps2, const float
 int upk_plms_step_f32(upk_ctx* ctx, float* x, const float* eps, const float* coefs, const int32_t* step,
                       float* hist, float* pred_x0, void* xin, int ld_xin, int batch, int c, int hw,
                       float cfg_scale, int cfg, upk_stream stream);
+/* With done != NULL the sampler step kernels launched afterwards (upk_ddim_step_f32, upk_ddim_step_cfg_f32,
+ * upk_plms_step_f32) add 1 to *step THEMSELVES once every workgroup has read it (done: a zero-initialised device
+ * int32 they use as arrival counter and leave at zero) — one launch less per sampler step than upk_advance_step.
+ * done == NULL restores the plain behaviour.  Host-side state of the context: set it around the calls. */
+int upk_step_autoadvance(upk_ctx* ctx, int32_t* done);
+
 /* *step += 1 (end of a captured step graph). */
 int upk_advance_step(upk_ctx* ctx, int32_t* step, upk_stream stream);
 

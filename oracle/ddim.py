@@ -48,6 +48,29 @@ def ddim_sample(eps_fn, alphas_cumprod_f32, shape, S, eta, x_T, noise=None, temp
 
 
 @torch.no_grad()
+def ddim_decode(eps_fn, alphas_cumprod_f32, x_latent, S, t_start, cond, uncond=None, guidance_scale=1.0,
+                num_ddpm=1000):
+    """DDIMSampler.decode (ddim.py:222-241): the last t_start steps of an S-step eta = 0 schedule applied to
+    x_latent (the img2img entry: stochastic_encode -> decode)."""
+    b = x_latent.shape[0]
+    ts, a, ap, sig, sq1m = ddim_step_coefficients(alphas_cumprod_f32, S, 0.0, num_ddpm)
+    steps = np.flip(ts[:t_start])
+    total = steps.shape[0]
+    x = x_latent
+    for i, step in enumerate(steps):
+        index = total - i - 1
+        t = torch.full((b,), int(step), dtype=torch.long)
+        if uncond is None or guidance_scale == 1.0:
+            e_t = eps_fn(x, t, cond)
+        else:
+            e_u = eps_fn(x, t, uncond)
+            e_t = e_u + guidance_scale * (eps_fn(x, t, cond) - e_u)
+        pred_x0 = (x - float(sq1m[index]) * e_t) / float(np.sqrt(np.float32(a[index])))
+        x = float(np.sqrt(np.float32(ap[index]))) * pred_x0 + float(np.sqrt(np.float32(1.0 - ap[index]))) * e_t
+    return x
+
+
+@torch.no_grad()
 def plms_sample(eps_fn, alphas_cumprod_f32, shape, S, x_T, cond=None, log_every_t=100, num_ddpm=1000):
     """ldm/models/diffusion/plms.py:114-236 (eta = 0): the DDIM update applied to an
     Adams-Bashforth combination of the current and up to three previous eps; the first step

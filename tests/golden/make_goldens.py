@@ -2,7 +2,7 @@
 """Generates the golden fixtures under tests/golden/ by running the REAL reference
 (/root/reference, pure Python, imported read-only) on CPU in the build container.
 
-    python tests/golden/make_goldens.py [--only tiny|bbox|upscale|schedule]
+    python tests/golden/make_goldens.py [--only tiny|bbox|upscale|schedule|encode|plms|extra]
 
 The reference never travels: only its OUTPUTS (small arrays) and state-dict key/shape
 manifests are committed.  Weights and inputs are regenerated from upgpt_amd/synth.py's
@@ -256,6 +256,90 @@ def gen_plms(kind, out):
     print("plms", kind, "->", out, z.shape)
 
 
+def gen_extra(out):
+    """Round-2 fixtures for paths the first set left unpinned (VERDICT r01 "missing" 1, 2 and "weak" parity i):
+      sq32/*   full bbox.yaml model on the BENCH shape — latent 32x32, text-only conditioning (null style, zero SMPL),
+               B = 1: one UNet forward and a 50-step eta = 0 DDIM run;
+      blend/*  DDIMSampler.sample(mask=, x0=) on the tiny model (ddim.py:144-147): the known region is re-noised with
+               q_sample every step — the harness feeds q_sample's noise so the run is reproducible on any device;
+      dec/*    DDIMSampler.decode (ddim.py:222-241) from t_start = 6 of a 10-step schedule (guided: on the xattn model);
+      xattn/*  a conditioning_key = "crossattn" tiny model driven exactly like scripts/txt2img.py:280-300: TENSOR
+               conditioning, tensor unconditional conditioning, guidance scale 3 (ddim.py:173-178)."""
+    g = {}
+    # ---- sq32
+    model, params = build_reference("bbox")
+    inp = synth.synth_inputs(1, (32, 32), 4, 87, 768, seed=21, text_only=True)
+    x, ctx, cc = inp["x_T"], inp["c_crossattn"], inp["c_concat"]
+    cond = {"c_crossattn": ctx, "c_concat": [cc]}
+    g["sq32/unet_eps"] = model.apply_model(x, torch.tensor([981]), cond).numpy()
+    ref_ddim.noise_like = NoiseFeed(None)
+    z, _ = ref_ddim.DDIMSampler(model).sample(S=50, batch_size=1, shape=(4, 32, 32), conditioning=cond, eta=0.0,
+                                              x_T=x.clone(), verbose=False)
+    g["sq32/ddim_S50/z"] = z.numpy()
+    g["sq32/crc_inputs"] = np.asarray([synth.crc_of(x), synth.crc_of(ctx), synth.crc_of(cc)], dtype=np.uint64)
+    del model
+    # ---- blend + decode on the tiny model
+    model, params = build_reference("tiny")
+    B, hw, S = 2, (32, 24), 10
+    inp = synth.synth_inputs(B, hw, 4, 87, 768, seed=5, steps=S)
+    cond = {"c_crossattn": inp["c_crossattn"], "c_concat": [inp["c_concat"]]}
+    x0 = 0.7 * synth.synth_inputs(B, hw, 4, 87, 768, seed=6)["x_T"]
+    mask = (synth.person_mask(B, *hw) > 0.5).float()  # 1 = keep x0
+    feed = NoiseFeed(inp["noise"])
+    q_orig = model.q_sample
+    model.q_sample = lambda x_start, t, noise=None: q_orig(x_start, t, noise=feed(None, None))
+    ref_ddim.noise_like = NoiseFeed(None)
+    z, _ = ref_ddim.DDIMSampler(model).sample(S=S, batch_size=B, shape=(4,) + hw, conditioning=cond, eta=0.0,
+                                              x_T=inp["x_T"].clone(), mask=mask, x0=x0, verbose=False)
+    model.q_sample = q_orig
+    g["blend/z"] = z.numpy()
+    g["blend/mask_sum"] = np.asarray(float(mask.sum()))
+    sampler = ref_ddim.DDIMSampler(model)
+    sampler.make_schedule(ddim_num_steps=S, ddim_eta=0.0, verbose=False)
+    ref_ddim.noise_like = NoiseFeed(None)
+    g["dec/x_dec"] = sampler.decode(inp["x_T"].clone(), cond, 6).numpy()
+    # (classifier-free guidance with DICT conditioning does not exist in the reference: p_sample_ddim concatenates
+    #  torch.cat([unconditional_conditioning, c]) and raises TypeError for dicts, ddim.py:176 — pinned below)
+    try:
+        sampler.decode(inp["x_T"].clone(), cond, 2, unconditional_guidance_scale=2.5, unconditional_conditioning=cond)
+        g["dict_cfg_raises"] = np.asarray(0)
+    except TypeError:
+        g["dict_cfg_raises"] = np.asarray(1)
+    del model
+    # ---- crossattn model, txt2img.py call shape
+    base = yaml.safe_load(open(os.path.join(REF, "configs/deepfashion/bbox.yaml")))["model"]["params"]
+    p = copy.deepcopy(base)
+    p["first_stage_config"]["params"]["ckpt_path"] = None
+    p["first_stage_config"]["params"]["ddconfig"]["ch"] = synth.TINY_DDCONFIG["ch"]
+    p["cond_stage_config"] = {"target": "ldm.modules.poses.poses.DummyModel"}
+    p.pop("extra_cond_stages")
+    p.pop("scheduler_config")
+    p["conditioning_key"] = "crossattn"
+    p["concat_key"] = None
+    p["unet_config"]["params"]["model_channels"] = synth.TINY_UNET["model_channels"]
+    p["unet_config"]["params"]["in_channels"] = 4
+    model = LatentDiffusion(**p).eval()
+    synth.fill_module_(model)
+    json.dump(manifest(model), open(os.path.join(HERE, "manifest_tiny_crossattn.json"), "w"), indent=0, sort_keys=True)
+    inp = synth.synth_inputs(B, hw, 4, 77, 768, seed=9)
+    c, start = inp["c_crossattn"], inp["x_T"]
+    uc_t = 0.1 * synth.synth_inputs(B, hw, 4, 77, 768, seed=10)["c_crossattn"]
+    g["xattn/unet_eps"] = model.apply_model(start, torch.tensor([981, 401]), c).numpy()
+    ref_ddim.noise_like = NoiseFeed(None)
+    z, _ = ref_ddim.DDIMSampler(model).sample(S=S, conditioning=c, batch_size=B, shape=(4,) + hw, verbose=False,
+                                              unconditional_guidance_scale=3.0, unconditional_conditioning=uc_t,
+                                              eta=0.0, x_T=start.clone())
+    g["xattn/z_cfg3"] = z.numpy()
+    g["xattn/img_pool8"] = pool8(model.decode_first_stage(z))
+    sampler = ref_ddim.DDIMSampler(model)
+    sampler.make_schedule(ddim_num_steps=S, ddim_eta=0.0, verbose=False)
+    ref_ddim.noise_like = NoiseFeed(None)
+    g["xattn/x_dec_cfg"] = sampler.decode(start.clone(), c, 6, unconditional_guidance_scale=2.5,
+                                          unconditional_conditioning=uc_t).numpy()
+    np.savez_compressed(out, **g)
+    print("extra ->", out, sorted(g))
+
+
 def gen_schedule(out):
     g = {}
     for name, (ls, le) in {"bbox": (0.00085, 0.012), "upscale": (0.0001, 0.02)}.items():
@@ -286,9 +370,11 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    kinds = [a.only] if a.only else ["schedule", "tiny", "bbox", "upscale", "encode", "plms"]
+    kinds = [a.only] if a.only else ["schedule", "tiny", "bbox", "upscale", "encode", "plms", "extra"]
     for k in kinds:
-        if k == "plms":
+        if k == "extra":
+            gen_extra(os.path.join(HERE, "extra.npz"))
+        elif k == "plms":
             for kind in ("tiny", "bbox"):
                 gen_plms(kind, os.path.join(HERE, "plms_%s.npz" % kind))
         elif k == "encode":

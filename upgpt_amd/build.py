@@ -3,6 +3,7 @@
 No torch / pybind dependency: the library is a plain C-ABI shared object
 (include/upk.h) loaded through ctypes by upgpt_amd/_lib.py.
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -23,13 +24,29 @@ def _hipcc():
     raise RuntimeError("hipcc not found: libupk.so cannot be built")
 
 
+def _source_hash():
+    """SHA-256 over every file of csrc/ and include/upk.h (names + contents) and the compile flags."""
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(HERE, "..", "include", "upk.h")]
+    for path in files:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update((ARCH + " " + os.environ.get("UPK_CXXFLAGS", "")).encode())
+    return h.hexdigest()
+
+
 def _stale():
-    if not os.path.exists(OUT):
+    """The library is rebuilt when it is missing, when UPK_FORCE_BUILD=1, or when the hash recorded next to it
+    (libupk.so.sha256, written by the build that produced it) differs from the hash of the sources — a shipped binary
+    that does not come from THESE sources is never reused (modification times say nothing on a fresh checkout)."""
+    if os.environ.get("UPK_FORCE_BUILD", "0") == "1" or not os.path.exists(OUT):
         return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
-    deps.append(os.path.join(HERE, "..", "include", "upk.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    try:
+        with open(OUT + ".sha256") as f:
+            return f.read().strip() != _source_hash()
+    except OSError:
+        return True
 
 
 def build(force=False, verbose=True):
@@ -62,6 +79,8 @@ def build(force=False, verbose=True):
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
     os.replace(OUT + ".tmp", OUT)
+    with open(OUT + ".sha256", "w") as f:
+        f.write(_source_hash() + "\n")
     return OUT
 
 

@@ -45,6 +45,7 @@ struct upk_ctx {
   int cfg_override;
   int splitk_override;
   void* tune_flush;  // 512 MB cache-flush buffer of the cold autotuner (allocated on first use)
+  int* step_done;    // upk_step_autoadvance: arrival counter of the sampler step kernels, or nullptr
   // profiling
   int prof_on;
   std::vector<upk_prof_rec> recs;       // recorded, not yet collected

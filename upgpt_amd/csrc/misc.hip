@@ -23,6 +23,7 @@ extern "C" int upk_create(upk_ctx** out, int device) {
   c->ws_bytes = 0;
   c->zero_page = nullptr;
   c->tune_flush = nullptr;
+  c->step_done = nullptr;
   {
     int cur = 0;
     (void)hipGetDevice(&cur);
@@ -168,54 +169,72 @@ __global__ void f32_to_f16_kernel(const float* x, int rows, int cols, f16* y, in
   y[r * ldy + cidx] = (f16)x[idx];
 }
 
+// The sampler step kernels advance the device-side step counter themselves (upk_step_autoadvance): every block has read
+// *step before it arrives at `done`; the block that arrives last bumps the counter and re-arms `done`.  One launch
+// less per step than a separate increment kernel; the next kernel sees the new value across the launch boundary.
+__device__ __forceinline__ void step_advance(const int* step, int* done) {
+  __syncthreads();
+  if (done && threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd((unsigned*)done, 1u) == gridDim.x - 1) {
+      *done = 0;
+      *(int*)step = *step + 1;
+    }
+  }
+}
+
 // ddim.py:189-203 in one launch (see include/upk.h for the coefficient table).
 __global__ void ddim_step_kernel(float* x, const float* eps, const float* coefs, const float* noise, const int* step,
-                                 float* pred_x0, f16* xin, int ld_xin, int c, int hw, long n) {
+                                 float* pred_x0, f16* xin, int ld_xin, int c, int hw, long n, int* done) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n) return;
   const int st = step ? *step : 0;
-  const float* cf = coefs + 4 * st;
-  const float c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
-  const float xv = x[idx], e = eps[idx];
-  const float p0 = (xv - c0 * e) * c1;
-  float xp = c2 * p0 + c3 * e;
-  if (noise) xp += noise[(long)st * n + idx];
-  x[idx] = xp;
-  if (pred_x0) pred_x0[idx] = p0;
-  if (xin) {
-    const long p = idx % hw;
-    const long t = idx / hw;
-    const long ch = t % c;
-    const long b = t / c;
-    xin[(b * hw + p) * ld_xin + ch] = (f16)xp;
+  if (idx < n) {
+    const float* cf = coefs + 4 * st;
+    const float c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
+    const float xv = x[idx], e = eps[idx];
+    const float p0 = (xv - c0 * e) * c1;
+    float xp = c2 * p0 + c3 * e;
+    if (noise) xp += noise[(long)st * n + idx];
+    x[idx] = xp;
+    if (pred_x0) pred_x0[idx] = p0;
+    if (xin) {
+      const long p = idx % hw;
+      const long t = idx / hw;
+      const long ch = t % c;
+      const long b = t / c;
+      xin[(b * hw + p) * ld_xin + ch] = (f16)xp;
+    }
   }
+  if (step) step_advance(step, done);
 }
 
 // Classifier-free guidance inside the update (ddim.py:173-178): the UNet ran on [uncond ; cond] (2*batch rows),
 // eps = e_u + scale * (e_c - e_u); the new latent refreshes BOTH halves of the UNet stem input.
 __global__ void ddim_step_cfg_kernel(float* x, const float* eps2, const float* coefs, const float* noise, const int* step,
-                                     float* pred_x0, f16* xin, int ld_xin, int c, int hw, long n, float scale) {
+                                     float* pred_x0, f16* xin, int ld_xin, int c, int hw, long n, float scale, int* done) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n) return;
   const int st = step ? *step : 0;
-  const float* cf = coefs + 4 * st;
-  const float c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
-  const float eu = eps2[idx], ec = eps2[n + idx];
-  const float xv = x[idx], e = eu + scale * (ec - eu);
-  const float p0 = (xv - c0 * e) * c1;
-  float xp = c2 * p0 + c3 * e;
-  if (noise) xp += noise[(long)st * n + idx];
-  x[idx] = xp;
-  if (pred_x0) pred_x0[idx] = p0;
-  if (xin) {
-    const long p = idx % hw;
-    const long t = idx / hw;
-    const long ch = t % c;
-    const long b = t / c;
-    const f16 h = (f16)xp;
-    xin[(b * hw + p) * ld_xin + ch] = h;
-    xin[(n / c + b * hw + p) * ld_xin + ch] = h;  // row offset batch*hw: the conditional half
+  if (idx < n) {
+    const float* cf = coefs + 4 * st;
+    const float c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
+    const float eu = eps2[idx], ec = eps2[n + idx];
+    const float xv = x[idx], e = eu + scale * (ec - eu);
+    const float p0 = (xv - c0 * e) * c1;
+    float xp = c2 * p0 + c3 * e;
+    if (noise) xp += noise[(long)st * n + idx];
+    x[idx] = xp;
+    if (pred_x0) pred_x0[idx] = p0;
+    if (xin) {
+      const long p = idx % hw;
+      const long t = idx / hw;
+      const long ch = t % c;
+      const long b = t / c;
+      const f16 h = (f16)xp;
+      xin[(b * hw + p) * ld_xin + ch] = h;
+      xin[(n / c + b * hw + p) * ld_xin + ch] = h;  // row offset batch*hw: the conditional half
+    }
   }
+  if (step) step_advance(step, done);
 }
 
 // One model evaluation of the PLMS sampler (plms.py:177-236), k = *step counts EVALUATIONS (S + 1 for S steps):
@@ -225,10 +244,11 @@ __global__ void ddim_step_cfg_kernel(float* x, const float* eps2, const float* c
 //           (3/2,-1/2 | 23/12,-16/12,5/12 | 55/24,-59/24,37/24,-9/24); x <- ddim(x, e', coef[j]); hist <- eps
 // eps may be the two halves of a classifier-free-guidance pass (eps2 = [uncond ; cond], scale), cfg_rows = 2.
 __global__ void plms_step_kernel(float* x, const float* eps, const float* coefs, const int* step, float* hist,
-                                 float* pred_x0, f16* xin, int ld_xin, int c, int hw, long n, int cfg_rows, float scale) {
+                                 float* pred_x0, f16* xin, int ld_xin, int c, int hw, long n, int cfg_rows, float scale,
+                                 int* done) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n) return;
   const int k = step ? *step : 0;
+  if (idx < n) {
   const int j = k == 0 ? 0 : k - 1;
   const float* cf = coefs + 4 * j;
   const float c0 = cf[0], c1 = cf[1], c2 = cf[2], c3 = cf[3];
@@ -273,6 +293,8 @@ __global__ void plms_step_kernel(float* x, const float* eps, const float* coefs,
     xin[(b * hw + p) * ld_xin + ch] = h;
     if (cfg_rows == 2) xin[(n / c + b * hw + p) * ld_xin + ch] = h;
   }
+  }
+  if (step) step_advance(step, done);
 }
 
 // ViT patch embedding, step 1 (CLIP image tower, Conv2d(3, width, patch, stride = patch, bias = False)): the
@@ -396,7 +418,7 @@ extern "C" int upk_ddim_step_f32(upk_ctx* ctx, float* x, const float* eps, const
   const long n = (long)batch * c * hw;
   upk_prof_scope prof(ctx, UPK_CLS_OTHER, (hipStream_t)stream_);
   hipLaunchKernelGGL(ddim_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x, eps,
-                     coefs, noise, step, pred_x0, (f16*)xin, ld_xin, c, hw, n);
+                     coefs, noise, step, pred_x0, (f16*)xin, ld_xin, c, hw, n, ctx->step_done);
   return upk_check_launch(ctx, "ddim_step");
 }
 
@@ -409,7 +431,7 @@ extern "C" int upk_ddim_step_cfg_f32(upk_ctx* ctx, float* x, const float* eps2, 
   const long n = (long)batch * c * hw;
   upk_prof_scope prof(ctx, UPK_CLS_OTHER, (hipStream_t)stream_);
   hipLaunchKernelGGL(ddim_step_cfg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x, eps2,
-                     coefs, noise, step, pred_x0, (f16*)xin, ld_xin, c, hw, n, scale);
+                     coefs, noise, step, pred_x0, (f16*)xin, ld_xin, c, hw, n, scale, ctx->step_done);
   return upk_check_launch(ctx, "ddim_step_cfg");
 }
 
@@ -423,7 +445,7 @@ extern "C" int upk_plms_step_f32(upk_ctx* ctx, float* x, const float* eps, const
   const long n = (long)batch * c * hw;
   upk_prof_scope prof(ctx, UPK_CLS_OTHER, (hipStream_t)stream_);
   hipLaunchKernelGGL(plms_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x, eps,
-                     coefs, step, hist, pred_x0, (f16*)xin, ld_xin, c, hw, n, cfg ? 2 : 1, cfg_scale);
+                     coefs, step, hist, pred_x0, (f16*)xin, ld_xin, c, hw, n, cfg ? 2 : 1, cfg_scale, ctx->step_done);
   return upk_check_launch(ctx, "plms_step");
 }
 
@@ -478,6 +500,12 @@ extern "C" int upk_gather_rows_f16(upk_ctx* ctx, const void* x, int ldx, const i
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
                      (const f16*)x, ldx, idx, n, n_src, dim, (f16*)y, ldy);
   return upk_check_launch(ctx, "gather_rows");
+}
+
+extern "C" int upk_step_autoadvance(upk_ctx* ctx, int32_t* done) {
+  if (!ctx) return UPK_EINVAL;
+  ctx->step_done = done;
+  return UPK_OK;
 }
 
 extern "C" int upk_advance_step(upk_ctx* ctx, int32_t* step, upk_stream stream_) {

@@ -134,6 +134,10 @@ class DDIMSampler(object):
                                                   self.ddim_sqrt_one_minus_alphas, order))
             sig = torch.as_tensor(np.asarray(self.ddim_sigmas, dtype=np.float64)).float()[torch.as_tensor(order)]
             with_noise = bool((sig != 0).any())
+            # RNG consumption follows the reference: p_sample_ddim draws noise_like(x.shape) in EVERY step, also when
+            # sigma_t == 0 (ddim.py:200, util.py:264-267), so after sample() the device generator has advanced by S
+            # draws of the latent's shape — a caller that seeds once and samples several batches (inference.ipynb)
+            # sees the same stream positions.  The S draws happen here, before the captured loop, one call per step.
             if with_noise:
                 nz = st.ensure_noise()
                 if normals_sequence is not None:
@@ -141,8 +145,12 @@ class DDIMSampler(object):
                         list(normals_sequence))
                     nz.copy_(ns.to(dev, torch.float32).reshape(S, -1))
                 else:
-                    nz.normal_()
+                    for i in range(S):
+                        nz[i].copy_(torch.randn(shape, device=dev).reshape(-1))
                 nz.mul_((sig * float(temperature)).to(dev)[:, None])
+            elif normals_sequence is None:
+                for i in range(S):
+                    torch.randn(shape, device=dev)  # (sigma = 0: the draw is discarded, as in the reference)
             plan.step.zero_()
             plan.prep.run()
             intermediates = {"x_inter": [st.x.clone()], "pred_x0": [st.x.clone()]}
@@ -260,9 +268,11 @@ class DDIMSampler(object):
         scal = lambda v: float(torch.as_tensor(v[index]).float())  # fp32 rounding, like torch.full(...)
         a_t, a_prev, sigma_t, sq1m = scal(alphas), scal(alphas_prev), scal(sigmas), scal(sqrt_1m)
         nz = None
+        if noise is None:  # drawn in every step, also for sigma_t == 0, like ddim.py:200 (same generator state after)
+            noise = noise_like(x.shape, device, repeat_noise)
+            if sigma_t == 0.:
+                noise = None
         if sigma_t != 0. or noise is not None:
-            if noise is None:
-                noise = noise_like(x.shape, device, repeat_noise)
             nz = sigma_t * noise * temperature
             if noise_dropout > 0.:
                 nz = torch.nn.functional.dropout(nz, p=noise_dropout)

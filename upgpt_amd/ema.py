@@ -35,13 +35,17 @@ class LitEma(nn.Module):
                     s.sub_((1.0 - decay) * (s - p))
 
     def copy_to(self, model):
-        for name, p in model.named_parameters():
-            if p.requires_grad:
-                p.data.copy_(self.shadow(name).data)
+        # in-place copy_ under no_grad (not `.data.copy_`): it bumps Tensor._version, which is what the packed-weight
+        # caches watch (upgpt_amd/params.py weights_fingerprint) — a `.data` write would leave stale fp16 packs
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                if p.requires_grad:
+                    p.copy_(self.shadow(name))
 
     def store(self, parameters):
         self.collected_params = [p.clone() for p in parameters]
 
     def restore(self, parameters):
-        for c, p in zip(self.collected_params, parameters):
-            p.data.copy_(c.data)
+        with torch.no_grad():
+            for c, p in zip(self.collected_params, parameters):
+                p.copy_(c)

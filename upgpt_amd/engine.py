@@ -420,7 +420,7 @@ class Emitter:
         else:
             out_mine = out is None
             if out is None:
-                ld = pw.n_out if pw.n_out % 8 == 0 else _rup(pw.n_out, 32)
+                ld = pw.n_out if pw.n_out % 32 == 0 else _rup(pw.n_out, 32)  # (a consumer conv reads 32-channel chunks)
                 out = Act(self.alloc(M, ld, zero=(ld != pw.n_out)), B, Ho, Wo, pw.n_out)
             d.y = out.t.data_ptr()
             d.ldy = out.ld
@@ -821,6 +821,13 @@ class UNetPlan(Emitter):
         self.conv(P, x, self.pk.w["out.2"], nchw_out=self.eps, gn=(*self.pk.v["out.0"], 1e-5, True, self.gn_ws))
 
     # ---- host-facing helpers
+    def close(self):
+        """Releases the graphs of the sampler states attached to this plan (ddim.py / plms.py fast paths)."""
+        for attr in ("_sampler_state", "_sampler_state_cfg", "_plms_state", "_plms_state_cfg"):
+            st = self.__dict__.pop(attr, None)
+            if st is not None:
+                st.close()
+
     def load_context(self, context):
         """context: [B, n_ctx, context_dim] tensor (any float dtype / device)."""
         assert tuple(context.shape) == (self.B, self.n_ctx, self.arch.context_dim), \
@@ -1046,7 +1053,14 @@ class SamplerState:
         self.coefs = plan.alloc(R, 4, dtype=torch.float32)
         self.noise = None
         self.graphs = {}
+        self.step_done = plan.alloc(1, dtype=torch.int32, zero=True)  # arrival counter of the step kernels
         self.hist = plan.alloc(3, B * channels * H * W, dtype=torch.float32) if plms else None
+
+    def close(self):
+        """Destroys the instantiated HIP graphs (they hold device memory; called when the owning plan is dropped)."""
+        for g in self.graphs.values():
+            self.plan.ctx.graph_destroy(g)
+        self.graphs = {}
 
     def ensure_noise(self):
         if self.noise is None:
@@ -1057,8 +1071,17 @@ class SamplerState:
     def _emit_tail(self, stream, with_noise, scale=1.0):
         p = self.plan
         nz = self.noise.data_ptr() if with_noise else None
+        # the step kernel also advances the device-side step counter (include/upk.h upk_step_autoadvance)
+        p.ctx._chk(p.lib.upk_step_autoadvance(p.hctx, self.step_done.data_ptr()))
+        try:
+            self._emit_step(stream, nz, scale)
+        finally:
+            p.ctx._chk(p.lib.upk_step_autoadvance(p.hctx, None))
+
+    def _emit_step(self, stream, nz, scale):
+        p = self.plan
         if self.plms:
-            assert not with_noise, "PLMS runs with eta = 0"
+            assert nz is None, "PLMS runs with eta = 0"
             p.ctx._chk(p.lib.upk_plms_step_f32(p.hctx, self.x.data_ptr(), p.eps.data_ptr(), self.coefs.data_ptr(),
                                                p.step.data_ptr(), self.hist.data_ptr(), self.pred_x0.data_ptr(),
                                                p.xin.t.data_ptr(), p.xin.ld, self.B, self.C, p.H * p.W, float(scale),
@@ -1071,7 +1094,6 @@ class SamplerState:
             p.ctx._chk(p.lib.upk_ddim_step_f32(p.hctx, self.x.data_ptr(), p.eps.data_ptr(), self.coefs.data_ptr(), nz,
                                                p.step.data_ptr(), self.pred_x0.data_ptr(), p.xin.t.data_ptr(), p.xin.ld,
                                                p.B, self.C, p.H * p.W, stream))
-        p.ctx._chk(p.lib.upk_advance_step(p.hctx, p.step.data_ptr(), stream))
 
     def step_eager(self, with_noise, scale=1.0):
         s = self.plan.ctx._s()

@@ -41,7 +41,9 @@ class ParamTree(ParamNode):
 
 def weights_fingerprint(module):
     """Cheap change detector for packed-weight caches: in-place updates bump
-    Tensor._version, replacement / device moves change data_ptr."""
+    Tensor._version, replacement / device moves change data_ptr.  Writes through `.data` (p.data.copy_(...)) bump
+    neither: after such an edit call the owning model's invalidate() (LitEma.copy_to / restore write through
+    torch.no_grad() + copy_ for exactly that reason)."""
     v, ptr = 0, 0
     for p in module.parameters():
         v += p._version

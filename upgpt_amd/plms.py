@@ -121,6 +121,8 @@ class PLMSSampler(DDIMSampler):
             plan.load_context(c_cross)
             st.coefs[:S].copy_(ddim_coefficient_table(self.ddim_alphas, self.ddim_alphas_prev, self.ddim_sigmas,
                                                       self.ddim_sqrt_one_minus_alphas, order))
+            for _ in range(S + 1):  # the reference draws (and, eta being 0, discards) one noise tensor per update:
+                torch.randn(shape, device=dev)  # plms.py get_x_prev_and_pred_x0 — same generator state afterwards
             plan.step.zero_()
             plan.prep.run()
             intermediates = {"x_inter": [st.x.clone()], "pred_x0": [st.x.clone()]}

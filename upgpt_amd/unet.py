@@ -64,7 +64,8 @@ class UNetModel(ParamTree):
             with torch.cuda.device(dev):
                 pk = PackedUNet(ctx, self.arch, get)
             self._packed[tag] = (fp, pk)
-            self._plans = {k: v for k, v in self._plans.items() if k[0] != tag}
+            for k in [k for k in self._plans if k[0] == tag]:
+                self._plans.pop(k).close()  # (plans of the old weight set: their captured graphs go with them)
         return ctx, tag, self._packed[tag][1]
 
     def plan(self, B, H, W, n_ctx, rows, mode):
@@ -74,7 +75,7 @@ class UNetModel(ParamTree):
         pl = self._plans.get(key)
         if pl is None:
             if len(self._plans) >= 8:  # bound device memory held by stale shapes
-                self._plans.pop(next(iter(self._plans)))
+                self._plans.pop(next(iter(self._plans))).close()
             with torch.cuda.device(ctx.device):
                 pl = UNetPlan(ctx, pk, B, H, W, n_ctx, rows, mode)
                 pl.apply_tuning(tune_missing=os.environ.get("UPGPT_AUTOTUNE", "0") == "1")
@@ -82,7 +83,10 @@ class UNetModel(ParamTree):
         return pl
 
     def invalidate(self):
+        """Drops the packed weights and every plan (call after editing parameters through `.data`)."""
         self._packed.clear()
+        for pl in self._plans.values():
+            pl.close()
         self._plans.clear()
 
     # ---- reference surface

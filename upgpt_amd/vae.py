@@ -69,7 +69,7 @@ class AutoencoderKL(ParamTree):
             self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
 
     def init_from_ckpt(self, path, ignore_keys=list()):
-        sd = torch.load(path, map_location="cpu")["state_dict"]
+        sd = torch.load(path, map_location="cpu", weights_only=False)["state_dict"]  # (trusted Lightning pickle)
         for k in list(sd.keys()):
             if any(k.startswith(ik) for ik in ignore_keys):
                 print("Deleting key {} from state_dict.".format(k))
