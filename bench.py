@@ -2,7 +2,9 @@
 """bench.py — the reference's headline metric on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1 without a torchrun environment: the script re-launches itself as
+   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...,
+   one rank per GPU over RCCL; under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as given)
 
 One "step" = one pass of the hot path over one batch per GPU: x_T -> 50 x (UNetModel forward
 + DDIM update) -> VAE decode -> images on the device (+ one RCCL all-gather of the images
@@ -27,6 +29,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F16_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_TBS = 8.0             # spec (6.3 TB/s measured for a float4 copy), same guide
+
+
+def relaunch_under_torchrun(n, argv):
+    """`python bench.py --gpus N` with no rendezvous in the environment: become
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("[bench] launching %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    os.execv(sys.executable, cmd)
 
 
 def log(*a):
@@ -61,15 +77,24 @@ def quiet(fn, *a, **k):
 
 
 def timed(fn, n, dev):
+    """EXACTLY n calls of fn between barrier + device synchronisation on both sides -> (seconds, last result)."""
     from upgpt_amd import dist as D
+    sync = (lambda: torch.cuda.synchronize(dev)) if torch.device(dev).type == "cuda" else (lambda: None)
     D.barrier()
-    torch.cuda.synchronize(dev)
+    sync()
     t0 = time.perf_counter()
     for _ in range(n):
         out = fn()
-    torch.cuda.synchronize(dev)
+    sync()
     D.barrier()
     return time.perf_counter() - t0, out
+
+
+def gathered(step_fn):
+    """One bench step of a rank = its own batch, then the ONE exchange of the path: the all-gather of the decoded
+    images (RCCL over xGMI; enqueued on the stream the decode ran on, inside the timed region)."""
+    from upgpt_amd import dist as D
+    return lambda: D.all_gather_images(step_fn())
 
 
 def kernel_class_profile(model, wl, reps=10):
@@ -113,21 +138,40 @@ def kernel_class_profile(model, wl, reps=10):
         for k, classes in names.items():
             n = sum(1 for c in body.cls if c in classes)
             out[k] = {"ms_per_fwd": full - timed(classes), "launches_per_fwd": n}
+        # GPU kernels per class of one eager pass (a split-K launch = kernel + reduce pass, a GroupNorm with its own
+        # statistics = 2): counted by the library (upk_kernel_launches)
+        for k, classes in list(names.items()) + [("all", None)]:
+            ctx.lib.upk_kernel_launches(ctx.h, 1)
+            if classes is None:
+                body.run(s.cuda_stream)
+            else:
+                body.run(s.cuda_stream, skip=tuple(c for c in set(body.cls) if c not in classes))
+            n = int(ctx.lib.upk_kernel_launches(ctx.h, 1))
+            if classes is None:
+                n_kernels = n
+            else:
+                out[k]["kernels_per_fwd"] = n
+        s.synchronize()
         plan.prep.run()  # the ablated replays left garbage in the activations
         torch.cuda.synchronize()
-    return out, body.igemm_flops, body.attn_flops, body.n_launch, full
+    return out, body.igemm_flops, body.attn_flops, n_kernels, full
+
+
+TRAFFIC_FILE = "profiles/r02_igemm_traffic.json"
 
 
 def igemm_traffic_bytes_per_launch():
-    """HBM-side bytes per igemm launch from the PMC passes of scripts/gpu_traffic.sh
-    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; rocprofv3 cannot run inside this process), or
-    None when the summary for the current kernels has not been collected."""
-    f = os.path.join(ROOT, "profiles", "r01_igemm_traffic.json")
+    """(bytes per igemm launch, provenance).  rocprofv3 cannot run inside this process, so the figure is the one the
+    PMC passes of scripts/gpu_traffic.sh produced for THIS round's kernels (FETCH_SIZE x2 gfx950 correction +
+    WRITE_SIZE, fabric-side) — read from the committed summary and labelled as such; None when it has not been
+    collected for the current kernels."""
     try:
-        with open(f) as fh:
-            return json.load(fh)["bytes_per_launch"]
+        with open(os.path.join(ROOT, TRAFFIC_FILE)) as fh:
+            d = json.load(fh)
+        return d["bytes_per_launch"], "%s (%s; collected at commit %s)" % (TRAFFIC_FILE, d.get("command", "PMC"),
+                                                                          d.get("commit", "?"))
     except Exception:
-        return None
+        return None, None
 
 
 def unet_forward_ms(model, wl, reps=20):
@@ -149,11 +193,23 @@ def unet_forward_ms(model, wl, reps=20):
     return dt * 1e3
 
 
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(hw, ddim_steps, batch):
-    """The CPU oracle (port of the reference algorithm, validated against the real reference
-    in tests/test_oracle_golden.py) timed on this host: a bounded sample (UNet forwards at the
-    bench batch + one B=1 decode), extrapolated to the metric's unit."""
-    from oracle import unet as o_unet, vae as o_vae
+    """The CPU oracle (port of the reference algorithm, pinned to the real reference in tests/test_oracle_golden.py)
+    timed on this host with SURVEY.md 8(d)'s protocol: CPU model and thread count, 1 warm-up + >= 3 timed UNet
+    forwards AT the bench batch (the CPU path is sub-linear in the batch: no scaling from a smaller one), one real
+    10-step DDIM loop + VAE decode at B = 1 (BASELINE configs[0]), then images/s extrapolated to the bench workload."""
+    from oracle import ddim as o_ddim, schedule as o_sched, unet as o_unet, vae as o_vae
     from upgpt_amd import arch, synth
     cores = min(os.cpu_count() or 1, 32)  # more threads only add oversubscription on this op mix
     torch.set_num_threads(cores)
@@ -163,26 +219,38 @@ def cpu_baseline(hw, ddim_steps, batch):
     inp = synth.synth_inputs(batch, hw, 4, 87, 768, seed=0, text_only=True)
     x = torch.cat([inp["x_T"], inp["c_concat"]], 1)
     t = torch.full((batch,), 981, dtype=torch.long)
-    sb = 2  # bounded sample: forwards at B=2, scaled linearly to the bench batch (per-sample independent work)
+    fwd = lambda n: o_unet.unet_forward(sd, synth.BBOX_UNET, x[:n], t[:n], inp["c_crossattn"][:n])
     t0 = time.perf_counter()
-    o_unet.unet_forward(sd, synth.BBOX_UNET, x[:1], t[:1], inp["c_crossattn"][:1])  # warm-up
+    fwd(batch)  # warm-up at the bench batch
     warm = time.perf_counter() - t0
-    n_fwd, t0 = 0, time.perf_counter()
-    while n_fwd < 2 or (time.perf_counter() - t0 < 10 and n_fwd < 6):
-        o_unet.unet_forward(sd, synth.BBOX_UNET, x[:sb], t[:sb], inp["c_crossattn"][:sb])
-        n_fwd += 1
-        if warm > 20:  # pathologically slow host: one sample is enough
+    times = []
+    while len(times) < 3 and (sum(times) < 20 or not times):
+        t0 = time.perf_counter()
+        fwd(batch)
+        times.append(time.perf_counter() - t0)
+        if warm > 15 and len(times) >= 1:  # pathologically slow host: keep the run bounded
             break
-    t_fwd = (time.perf_counter() - t0) / n_fwd * (batch / sb)
+    t_fwd = min(times)
+    # BASELINE configs[0]: single sample, 10-step DDIM + decode, for real
+    acp = o_sched.ddpm_tables(o_sched.linear_betas(1000, 0.00085, 0.012))["alphas_cumprod"]
+    eps_fn = lambda xx, tt, c: o_unet.diffusion_wrapper(sd, synth.BBOX_UNET, xx, tt, c["c_concat"], c["c_crossattn"])
+    cond1 = {"c_crossattn": inp["c_crossattn"][:1], "c_concat": [inp["c_concat"][:1]]}
     t0 = time.perf_counter()
-    o_vae.decode_first_stage(sd, synth.BBOX_DDCONFIG, inp["x_T"][:1])
+    z, _ = o_ddim.ddim_sample(eps_fn, acp, (1, 4) + tuple(hw), 10, 0.0, inp["x_T"][:1].clone(), cond=cond1)
+    t_loop = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    o_vae.decode_first_stage(sd, synth.BBOX_DDCONFIG, z)
     t_dec = time.perf_counter() - t0
     total = ddim_steps * t_fwd + batch * t_dec
-    return {"value": batch / total, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d UNet forwards at B=%d latent %dx%d scaled x%d to B=%d (%.2f s per B=%d forward) + one B=1 "
-                      "VAE decode (%.2f s), fp32 torch-CPU oracle on %d threads, extrapolated to %d steps + %d decodes" % (
-                          n_fwd, sb, hw[0], hw[1], batch // sb, batch, t_fwd, batch, t_dec, cores, ddim_steps, batch),
-            "unet_fwd_s": t_fwd, "decode_b1_s": t_dec}
+    gf = arch.UNetArch(**synth.BBOX_UNET).flops(batch, hw[0], hw[1], 87) / 1e9
+    return {"value": batch / total, "unit": "images/s", "cores": cores, "kind": "port", "cpu": cpu_model_name(),
+            "sample": "1 warm-up + %d timed UNet forwards at B=%d latent %dx%d (best %.2f s = %.2f TFLOP/s) and one real "
+                      "10-step DDIM loop + VAE decode at B=1 (%.2f s + %.2f s: BASELINE configs[0]); fp32 torch-CPU "
+                      "oracle on %d threads; value = %d / (%d x forward + %d x decode)" % (
+                          len(times), batch, hw[0], hw[1], t_fwd, gf / t_fwd / 1e3, t_loop, t_dec, cores, batch,
+                          ddim_steps, batch),
+            "unet_fwd_s": t_fwd, "unet_fwd_times_s": times, "decode_b1_s": t_dec,
+            "config0_single_sample_10step_s": t_loop + t_dec}
 
 
 def encoders_secondary(model, wl, dev):
@@ -270,9 +338,15 @@ def main():
                     help="also time BASELINE configs[4]: the upscale UNet, bs=4, 64x64 latent, 50-step DDIM (UNet loop only)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args.gpus, sys.argv[1:])  # (does not return)
     from upgpt_amd import dist as D
-    rank, local_rank, world = D.init_from_env("nccl" if args.gpus > 1 else None)
-    assert world == args.gpus, "WORLD_SIZE %d != --gpus %d (launch with torch.distributed.run)" % (world, args.gpus)
+    rank, local_rank, world = D.env_world()
+    assert world == args.gpus, "WORLD_SIZE %d != --gpus %d" % (world, args.gpus)
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py needs an MI355X per rank: rank %d sees %d GPU(s); there is no CPU fallback" % (
+            rank, torch.cuda.device_count() if torch.cuda.is_available() else 0))
+    D.init_from_env("nccl" if args.gpus > 1 else None)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -286,9 +360,7 @@ def main():
     log("[bench] rank %d model ready in %.1fs" % (rank, time.time() - t0))
     wl = Workload(model, args.batch, hw, args.ddim_steps, seed=rank)
 
-    def step():
-        img = quiet(wl.run)
-        return D.all_gather_images(img)
+    step = gathered(lambda: quiet(wl.run))
 
     for _ in range(args.warmup):
         step()
@@ -311,23 +383,32 @@ def main():
         a = arch.UNetArch(**synth.BBOX_UNET)
         flops_fwd = a.flops(args.batch, hw[0], hw[1], 87)
         fwd_ms = unet_forward_ms(model, wl)
-        prof, ig_flops, at_flops, n_launch, body_ms = kernel_class_profile(model, wl)
+        prof, ig_flops, at_flops, n_kernels, body_ms = kernel_class_profile(model, wl)
         ig_ms = prof["igemm"]["ms_per_fwd"]
         achieved = ig_flops / (ig_ms * 1e-3) / 1e12
+        traffic, traffic_src = igemm_traffic_bytes_per_launch()
+        t_model, f_model, b_model = arch.unet_layer_roofline(a, args.batch, hw[0], hw[1], 87, PEAK_MFMA_F16_TFLOPS * 1e12,
+                                                             PEAK_HBM_TBS * 1e12)
+        n_api, n_k = prof["igemm"]["launches_per_fwd"], prof["igemm"]["kernels_per_fwd"]
         result["roofline"] = {
             "bound": "mfma",
-            "kernel": "igemm_ws_kernel<*> + igemm_kernel<*> + igemm_reduce[_gn]_kernel (implicit-GEMM conv/linear, every "
-                      "tile config, split-K reduce passes incl. the GroupNorm statistics they emit; 194 launches per UNet "
-                      "forward)",
+            "kernel": "igemm_ws_kernel<*> + igemm_kernel<*> + igemm_reduce[_gn]_kernel (implicit-GEMM conv / Linear, every "
+                      "tile configuration, with the split-K reduce passes and the GroupNorm statistics they emit): %d "
+                      "conv/GEMM launches = %d kernels per UNet forward" % (n_api, n_k),
             "method": "graph-replay difference: (forward) - (forward without the class), HIP events on the launch stream",
             "achieved": achieved, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F16_TFLOPS,
-            "traffic": igemm_traffic_bytes_per_launch(),
-            "algorithmic_flops_per_fwd": ig_flops, "avg_launch_us": ig_ms * 1e3 / max(1.0, prof["igemm"]["launches_per_fwd"]),
-            "launches_per_fwd": prof["igemm"]["launches_per_fwd"],
+            "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_flops_per_fwd": ig_flops, "launches_per_fwd": n_api, "kernels_per_fwd": n_k,
+            "avg_launch_us": ig_ms * 1e3 / max(1, n_api), "avg_kernel_us": ig_ms * 1e3 / max(1, n_k),
+            # the honest ceiling of the WHOLE forward, per layer max(MFMA time, HBM time)
+            "layer_model_ms": t_model * 1e3, "layer_model_bytes_per_fwd": b_model,
+            "frac_layer": t_model * 1e3 / fwd_ms,
         }
         result["unet"] = {"fwd_ms_graph": fwd_ms, "body_ms_graph": body_ms, "algorithmic_gflop_per_fwd": flops_fwd / 1e9,
                           "mfma_util": flops_fwd / (fwd_ms * 1e-3) / (PEAK_MFMA_F16_TFLOPS * 1e12),
-                          "kernel_launches_per_fwd": n_launch, "class_ms_per_fwd": {k: v["ms_per_fwd"] for k, v in prof.items()}}
+                          "kernel_launches_per_fwd": n_kernels,
+                          "class_ms_per_fwd": {k: v["ms_per_fwd"] for k, v in prof.items()},
+                          "class_kernels_per_fwd": {k: v["kernels_per_fwd"] for k, v in prof.items()}}
         tdec, _ = timed(lambda: model.decode_first_stage(wl.x_T), 3, dev) if world == 1 else (None, None)
         if tdec is not None:
             result["vae_decode_ms"] = tdec / 3 * 1e3

@@ -347,6 +347,10 @@ int upk_plms_step_f32(upk_ctx* ctx, float* x, const float* eps, const float* coe
  * done == NULL restores the plain behaviour.  Host-side state of the context: set it around the calls. */
 int upk_step_autoadvance(upk_ctx* ctx, int32_t* done);
 
+/* Number of GPU kernels enqueued through this context since creation / the last reset (a split-K conv is two, a
+ * GroupNorm with its own statistics pass is two): what bench.py reports as kernels per UNet forward. */
+long long upk_kernel_launches(upk_ctx* ctx, int reset);
+
 /* *step += 1 (end of a captured step graph). */
 int upk_advance_step(upk_ctx* ctx, int32_t* step, upk_stream stream);
 

@@ -1,0 +1,30 @@
+#!/bin/bash
+# A/B on one box: UNet forward (graph replay) with the patch kernel off / only for GroupNorm->proj_in / auto
+R=$GRAFT_REPO_ROOT; cd $R
+for mode in 0 k1 auto 0 k1; do
+  UPGPT_PCONV=$mode python - <<'PY' 2>/dev/null | tail -1
+import contextlib, io, os, sys, time, torch
+sys.path.insert(0, os.getcwd())
+import upgpt_amd
+from upgpt_amd import synth
+from upgpt_amd.engine import SamplerState
+with contextlib.redirect_stdout(io.StringIO()):
+    model = upgpt_amd.build_model("bbox")
+synth.fill_module_(model); model = model.cuda()
+unet = model.model.diffusion_model
+inp = synth.synth_inputs(8, (32, 32), 4, 87, 768, seed=0, text_only=True)
+pl = unet.plan(8, 32, 32, 87, 50, "sampler")
+pl.load_x_nchw(inp["x_T"].cuda(), 0, 0); pl.load_x_nchw(inp["c_concat"].cuda(), 4, pl.cin_pad)
+pl.load_context(inp["c_crossattn"].cuda()); pl.t_rows.copy_(torch.arange(981, 0, -20, dtype=torch.float32)[:50])
+pl.prep.run()
+st = SamplerState(pl, 4); st.x.copy_(inp["x_T"].cuda()); st.coefs.fill_(0.5)
+st.launch(False); torch.cuda.synchronize()
+best = 1e9
+for rep in range(3):
+    pl.step.zero_(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(40): st.launch(False)
+    torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / 40 * 1e3)
+print("UPGPT_PCONV=%s  forward %.3f ms  ops %d" % (os.environ["UPGPT_PCONV"], best, len(pl.body.ops)))
+PY
+done

@@ -1,13 +1,11 @@
 #!/bin/bash
-# One GPU-box session: tests, smoke, bench, rocprof kernel trace. Outputs under gpurun_out/.
-set -x
-mkdir -p gpurun_out
-export TMPDIR=/tmp
-F='^DDIM\|Running in\|params\.\|Keeping\|Data shape\|Running DDIM\|Plotting'
-timeout 900 python -m pytest tests -m gpu -q --timeout 600 2>&1 | grep -v "$F" | tail -15 > gpurun_out/pytest_gpu.log
-tail -5 gpurun_out/pytest_gpu.log
-timeout 300 python __graft_entry__.py smoke 2>&1 | grep -v "$F" | tail -5 > gpurun_out/smoke.log; cat gpurun_out/smoke.log
-timeout 900 python bench.py --steps 3 --warmup 1 > gpurun_out/bench.json 2> gpurun_out/bench.err; cat gpurun_out/bench.json; tail -3 gpurun_out/bench.err
-cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof.err
-cd $GRAFT_REPO_ROOT; find /tmp/prof -name "*stats*" | head; for f in $(find /tmp/prof -name "*kernel_stats.csv"); do cp $f gpurun_out/kernel_stats.csv; done
-head -40 gpurun_out/kernel_stats.csv
+# one GPU session: full -m gpu suite, smoke, bench (driver's command), rocprof kernel stats of the bench, op trace, traffic
+mkdir -p gpurun_out; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+cd $R
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log
+timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; tail -2 gpurun_out/smoke.log
+timeout 900 python bench.py --steps 5 --warmup 2 > gpurun_out/bench_r02.json 2> gpurun_out/bench_r02.err; tail -c 600 gpurun_out/bench_r02.json
+bash scripts/gpu_prof.sh > gpurun_out/prof.log 2>&1
+bash scripts/gpu_optrace.sh 32 32 > /dev/null 2>&1; tail -8 gpurun_out/ot_table_32x32.txt
+bash scripts/gpu_traffic.sh > gpurun_out/traffic.log 2>&1; tail -5 gpurun_out/traffic.log

@@ -49,7 +49,7 @@ for name, B, H, W, cin, cout, ks, flags in SHAPES:
     res.sort()
     print("== %s  %.2f GF" % (name, gf))
     for us, cfg, sk in res[:6]:
-        print("   %7.1f us  %6.0f TF/s  cfg %-9s sk %d" % (us, gf / us * 1e-3 * 1e3, lib.upk_conv_config_name(cfg).decode(), sk))
+        print("   %7.1f us  %6.0f TF/s  cfg %-9s sk %d" % (us, gf / us * 1e3, lib.upk_conv_config_name(cfg).decode(), sk))  # GF / us = 1e3 TF/s
     nosplit = [r for r in res if r[2] == 1][:3]
     for us, cfg, sk in nosplit:
-        print("   (no split) %7.1f us  %6.0f TF/s  cfg %s" % (us, gf / us, lib.upk_conv_config_name(cfg).decode()))
+        print("   (no split) %7.1f us  %6.0f TF/s  cfg %s" % (us, gf / us * 1e3, lib.upk_conv_config_name(cfg).decode()))

@@ -116,7 +116,7 @@ def main():
             us = e0.elapsed_time(e1) * 1e3 / reps / 3
             res.append((us, ctx.lib.upk_pconv_config_name(cfg).decode(), cfg))
         for us, nm, cfg in sorted(res):
-            print("   %7.1f us  %6.0f TF/s  %5.2f TB/s(w)   cfg %2d %s" % (us, gf / us, wbytes / us / 1e6, cfg, nm), flush=True)
+            print("   %7.1f us  %6.0f TF/s  %5.2f TB/s(w)   cfg %2d %s" % (us, gf / us * 1e3, wbytes / us / 1e6, cfg, nm), flush=True)
 
 
 if __name__ == "__main__":

@@ -56,3 +56,67 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
     assert D.all_gather_images(torch.ones(2, 3)) is not None  # no process group: identity
+
+
+def _bench_worker(rank, world, port, q, backend):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import bench
+    D.init_from_env(backend)
+    dev = torch.device("cuda", rank) if backend == "nccl" else torch.device("cpu")
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+    stub = lambda: torch.full((2, 3, 4, 4), float(rank), device=dev)  # stand-in for sample + decode of the rank's batch
+    dt, out = bench.timed(bench.gathered(stub), 3, dev)
+    dt = D.max_over_ranks(dt, dev)
+    ok = out.shape[0] == 2 * world and all(bool((out[2 * r:2 * r + 2] == r).all()) for r in range(world))
+    q.put((rank, ok, dt > 0))
+    dist.destroy_process_group()
+
+
+def _run_bench_workers(backend):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q, backend)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, True, True), (1, True, True)]
+
+
+def test_bench_step_gather_and_timing_two_ranks_gloo():
+    """bench.py's timed region for N > 1 — step, all-gather of the images, barrier, max over ranks — with a stub
+    workload on two gloo ranks."""
+    _run_bench_workers("gloo")
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_step_gather_two_ranks_rccl():
+    """The same over RCCL (backend "nccl"); needs two GPUs, skipped on the 1-GPU test boxes."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    _run_bench_workers("nccl")
+
+
+def test_bench_self_launches_its_ranks_and_fails_only_for_lack_of_gpus():
+    """`python bench.py --gpus 2` with no torchrun environment re-launches itself under torch.distributed.run (one rank
+    per GPU); on a box without GPUs every rank stops at the GPU check — not at a WORLD_SIZE assertion."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    err = r.stderr
+    assert "launching 2 ranks" in err and "torch.distributed.run" in err
+    assert "needs an MI355X per rank" in err
+    assert "AssertionError" not in err and r.returncode != 0

@@ -24,7 +24,7 @@ SYMBOLS = [
     "upk_nchw_f32_to_nhwc_f16", "upk_nhwc_f16_to_nchw_f32", "upk_f32_to_f16", "upk_ddim_step_f32",
     "upk_ddim_step_cfg_f32", "upk_plms_step_f32", "upk_attention_causal_f16", "upk_embed_tokens_f16",
     "upk_patchify_nchw_f32_f16", "upk_vit_assemble_f16", "upk_gather_rows_f16",
-    "upk_advance_step", "upk_step_autoadvance", "upk_graph_begin", "upk_graph_end", "upk_graph_launch", "upk_graph_destroy",
+    "upk_advance_step", "upk_step_autoadvance", "upk_kernel_launches", "upk_graph_begin", "upk_graph_end", "upk_graph_launch", "upk_graph_destroy",
     "upk_prof_enable", "upk_prof_collect",
 ]
 
@@ -129,6 +129,7 @@ def load_library(path=None):
             "upk_plms_step_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
             "upk_advance_step": (C.c_int, [vp, vp, vp]),
             "upk_step_autoadvance": (C.c_int, [vp, vp]),
+            "upk_kernel_launches": (C.c_longlong, [vp, i32]),
             "upk_graph_begin": (C.c_int, [vp, vp]),
             "upk_graph_end": (C.c_int, [vp, vp, C.POINTER(vp)]),
             "upk_graph_launch": (C.c_int, [vp, vp, vp]),

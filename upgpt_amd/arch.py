@@ -211,6 +211,63 @@ class UNetArch:
         return f
 
 
+def unet_layer_roofline(arch, batch, h, w, n_ctx, peak_flops=2.5e15, peak_bw=8.0e12):
+    """SURVEY.md 8(d)'s honest ceiling of one UNet forward: sum over the GEMM-shaped ops (conv, Linear, QK^T, PV) of
+    max(FLOP / dense fp16 MFMA peak, un-fused fp16 bytes / HBM peak) — each op reads its operands and writes its result
+    once.  Returns (seconds, flops, bytes).  About 42 % of the FLOPs of bbox.yaml at bs = 8 sit in ops whose weight
+    read takes longer than their MFMA time, which is why the MFMA-only figure is not the yardstick."""
+    te, mc = arch.time_embed_dim, arch.model_channels
+    tot = [0.0, 0, 0]
+
+    def op(flops, nbytes):
+        tot[0] += max(flops / peak_flops, nbytes / peak_bw)
+        tot[1] += flops
+        tot[2] += nbytes
+
+    def gemm(M, K, N):
+        op(2 * M * K * N, 2 * (M * K + K * N + M * N))
+
+    def attn(B, nq, nkv, c):  # all heads: QK^T + PV; q, k, v read, out written
+        op(2 * 2 * B * nq * nkv * c, 2 * (2 * B * nq * c + 2 * B * nkv * c))
+
+    gemm(batch, mc, te)
+    gemm(batch, te, te)
+    hw = [h, w]
+    pix = lambda: batch * hw[0] * hw[1]
+    for L in arch.all_layers():
+        if L.kind == "conv":
+            gemm(pix(), 9 * L.cin, L.cout)
+        elif L.kind == "res":
+            gemm(pix(), 9 * L.cin, L.cout)
+            gemm(batch, te, L.cout)
+            gemm(pix(), 9 * L.cout, L.cout)
+            if L.cin != L.cout:
+                gemm(pix(), L.cin, L.cout)
+        elif L.kind == "st":
+            n, c, cd = hw[0] * hw[1], L.ch, L.context_dim
+            gemm(pix(), c, c)  # proj_in
+            for _ in range(L.depth):
+                for _ in range(4):  # attn1 q, k, v, out
+                    gemm(pix(), c, c)
+                attn(batch, n, n, c)
+                gemm(pix(), c, c)  # attn2 q
+                gemm(batch * n_ctx, cd, c)
+                gemm(batch * n_ctx, cd, c)
+                attn(batch, n, n_ctx, c)
+                gemm(pix(), c, c)  # attn2 out
+                gemm(pix(), c, 8 * c)  # GEGLU projection
+                gemm(pix(), 4 * c, c)  # FF out
+            gemm(pix(), c, c)  # proj_out
+        elif L.kind == "down":
+            hw[0], hw[1] = (hw[0] + 2 - 3) // 2 + 1, (hw[1] + 2 - 3) // 2 + 1
+            gemm(pix(), 9 * L.ch, L.ch)
+        elif L.kind == "up":
+            hw[0], hw[1] = hw[0] * 2, hw[1] * 2
+            gemm(pix(), 9 * L.ch, L.ch)
+    gemm(pix(), 9 * mc, arch.out_channels)
+    return tot[0], tot[1], tot[2]
+
+
 class VAEArch:
     """AutoencoderKL ddconfig (autoencoder.py:286-306, model.py Encoder 368-432 / Decoder 462-533)."""
 

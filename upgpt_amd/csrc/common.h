@@ -46,6 +46,7 @@ struct upk_ctx {
   int splitk_override;
   void* tune_flush;  // 512 MB cache-flush buffer of the cold autotuner (allocated on first use)
   int* step_done;    // upk_step_autoadvance: arrival counter of the sampler step kernels, or nullptr
+  long long n_kernels;  // kernels enqueued through this context (upk_kernel_launches)
   // profiling
   int prof_on;
   std::vector<upk_prof_rec> recs;       // recorded, not yet collected
@@ -99,6 +100,7 @@ struct upk_prof_scope {
 };
 
 static inline int upk_check_launch(upk_ctx* ctx, const char* what) {
+  if (ctx) ++ctx->n_kernels;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return upk_fail(ctx, UPK_EHIP, "launch of %s failed: %s", what, hipGetErrorString(e));
   return UPK_OK;

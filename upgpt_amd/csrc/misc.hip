@@ -24,6 +24,7 @@ extern "C" int upk_create(upk_ctx** out, int device) {
   c->zero_page = nullptr;
   c->tune_flush = nullptr;
   c->step_done = nullptr;
+  c->n_kernels = 0;
   {
     int cur = 0;
     (void)hipGetDevice(&cur);
@@ -500,6 +501,13 @@ extern "C" int upk_gather_rows_f16(upk_ctx* ctx, const void* x, int ldx, const i
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
                      (const f16*)x, ldx, idx, n, n_src, dim, (f16*)y, ldy);
   return upk_check_launch(ctx, "gather_rows");
+}
+
+extern "C" long long upk_kernel_launches(upk_ctx* ctx, int reset) {
+  if (!ctx) return -1;
+  const long long n = ctx->n_kernels;
+  if (reset) ctx->n_kernels = 0;
+  return n;
 }
 
 extern "C" int upk_step_autoadvance(upk_ctx* ctx, int32_t* done) {

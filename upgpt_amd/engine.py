@@ -333,11 +333,13 @@ class Emitter:
         appended 1x1 segment (36 vs 33) stay on the split-K implicit GEMM.  UPGPT_PCONV=all forces it everywhere."""
         if PCONV_MODE == "all":
             return True
+        if PCONV_MODE == "k1":  # only the GroupNorm -> proj_in pairs (1x1, no SiLU, no halo)
+            return ks == 1
         if appended:
             return False
         if ks == 3:
             return M >= 8192 or (M >= 2048 and not concat)
-        return M >= 8192
+        return True
 
     def ln_linear(self, P, x, name, norm, flags=0, **kw):
         """LayerNorm `norm` followed by the Linear `name`: either one launch with the norm folded into the
@@ -903,10 +905,10 @@ class VAEDecodePlan(Emitter):
             if Lr.kind == "conv":
                 x = self.conv(P, x, W_[n])
             elif Lr.kind == "resnet":
-                h1 = self.conv(P, x, W_[n + ".conv1"], gn=(*V_[n + ".norm1"], 1e-6, True, self.gn_ws), gn_stats=True)
+                h1 = self.conv(P, x, W_[n + ".conv1"], gn=(*V_[n + ".norm1"], 1e-6, True, self.gn_ws), gn_stats=PCONV_ON)
                 sk = self.conv(P, x, W_[n + ".nin_shortcut"]) if Lr.cin != Lr.cout else x
                 x = self.conv(P, h1, W_[n + ".conv2"], residual=sk, gn=(*V_[n + ".norm2"], 1e-6, True, self.gn_ws),
-                              gn_stats=True)
+                              gn_stats=PCONV_ON)
             elif Lr.kind == "attn":
                 c, HW = Lr.ch, x.H * x.W
                 xn = self.groupnorm(P, x, *V_[n + ".norm"], 1e-6, False, self.gn_ws)
@@ -997,10 +999,10 @@ class VAEEncodePlan(Emitter):
             if Lr.kind == "conv":
                 x = self.conv(P, x, W_[n])
             elif Lr.kind == "resnet":
-                h1 = self.conv(P, x, W_[n + ".conv1"], gn=(*V_[n + ".norm1"], 1e-6, True, self.gn_ws), gn_stats=True)
+                h1 = self.conv(P, x, W_[n + ".conv1"], gn=(*V_[n + ".norm1"], 1e-6, True, self.gn_ws), gn_stats=PCONV_ON)
                 sk = self.conv(P, x, W_[n + ".nin_shortcut"]) if Lr.cin != Lr.cout else x
                 x = self.conv(P, h1, W_[n + ".conv2"], residual=sk, gn=(*V_[n + ".norm2"], 1e-6, True, self.gn_ws),
-                              gn_stats=True)
+                              gn_stats=PCONV_ON)
             elif Lr.kind == "attn":
                 c, HW = Lr.ch, x.H * x.W
                 xn = self.groupnorm(P, x, *V_[n + ".norm"], 1e-6, False, self.gn_ws)
