@@ -180,6 +180,19 @@ typedef struct upk_conv_desc {
   const float* gni_stats1;
   const float* gni_stats2;
   int32_t gni_nblk1, gni_ld1, gni_nblk2, gni_ld2;
+  /* GroupNorm (+ SiLU) of the OUTPUT applied by the split-K reduce pass (gn_fused mode 3): when this launch splits
+   * K (tuned / cost-model choice) and its epilogue is plain (bias + timestep row vector + residual -> fp16 NHWC),
+   * the reduce pass runs one workgroup per (sample, group): it sums the slabs, writes y (unless gno_skip_y: nobody
+   * but the GroupNorm reads it), takes the group's mean / variance from the fp16-rounded values it holds in
+   * registers and writes SiLU?(GroupNorm(y)) * gamma + beta to gno_y (row stride gno_ld) — the GroupNorm launch
+   * that would follow (ResBlock in_layers / out_layers, openaimodel.py:255-275; SpatialTransformer.norm,
+   * attention.py:250) is not needed.  gn_groups gives the group count.  Launches that do not split K ignore these
+   * fields (upk_conv_gn_fused reports what will happen). */
+  const float* gno_gamma;
+  const float* gno_beta;
+  void* gno_y;
+  float gno_eps;
+  int32_t gno_silu, gno_ld, gno_skip_y;
 } upk_conv_desc;
 
 /* Replaces F.conv2d (3x3 s1/s2 p1, 1x1) / F.linear call sites:
@@ -191,7 +204,8 @@ typedef struct upk_conv_desc {
 int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream);
 
 /* Which GroupNorm by-product upk_conv2d_nhwc_f16(d) will leave in d->gn_stats_ws (see upk_conv_desc): *mode in
- * {0, 1, 2}, *nblk = row blocks per sample for mode 2.  Nothing is enqueued. */
+ * {0, 1, 2, 3}, *nblk = row blocks per sample for mode 2; 3 = the reduce pass applies the GroupNorm itself (gno_*) and
+ * leaves no statistics.  Nothing is enqueued. */
 int upk_conv_gn_fused(upk_ctx* ctx, const upk_conv_desc* d, int* mode, int* nblk);
 
 /* Tile configurations of the A-stationary patch kernel (upk_conv_desc.pc_enable / pc_cfg). */

@@ -763,3 +763,67 @@ def test_errors_are_reported(ctx):
     with pytest.raises(L.UpkError) as ei:
         ctx.gemm(a, 40, 16, 40, a, 16, 16, None, None, 0, a, 16, 0)  # K not a multiple of 32
     assert ei.value.code == -2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,cin,cout,ks,sk,res,rv,silu,skip_y", [
+    (4, 4, 896, 896, 3, 9, False, True, True, True),     # level-3 ResBlock conv1 -> out_layers norm (cpg 28, 1 vector/thread)
+    (8, 8, 896, 896, 3, 9, True, False, True, False),    # level-2 conv2 + residual -> next block's norm
+    (8, 6, 448, 896, 3, 4, False, True, True, False),    # 256x192 level 2
+    (8, 8, 448, 896, 1, 2, True, False, False, False),    # SpatialTransformer.norm behind a split 1x1 (no SiLU)
+    (16, 16, 448, 448, 3, 4, True, False, False, False),  # cpg 14 / 7 / 2: outside the fused pass (it measured slower
+    (32, 32, 224, 224, 3, 4, False, False, True, False),  # there): plain reduce, request ignored and reported so
+    (16, 12, 256, 64, 1, 2, True, True, True, False),
+])
+def test_splitk_reduce_applies_groupnorm(ctx, H, W, cin, cout, ks, sk, res, rv, silu, skip_y):
+    """include/upk.h gno_*: the reduce pass of a split-K conv writes y AND SiLU?(GroupNorm32(y)); a launch that does not
+    split K ignores the request and reports so."""
+    B = 2
+    x = rnd(B, cin, H, W)
+    w = rnd(cout, cin, ks, ks, scale=1 / math.sqrt(ks * ks * cin))
+    b = rnd(cout, scale=0.1)
+    gamma, beta = rnd(cout, seed=3) * 0.5 + 1.0, rnd(cout, seed=4) * 0.3
+    resid = rnd(B, H, W, cout, seed=7).half() if res else None
+    rowv = rnd(3, B, cout, seed=8) if rv else None  # [step][sample][channel], step counter on the device
+    step = torch.tensor([2], device=DEV, dtype=torch.int32) if rv else None
+    ref = F.conv2d(x.half().float(), w.half().float(), b, padding=ks // 2)
+    if res:
+        ref = ref + resid.float().permute(0, 3, 1, 2)
+    if rv:
+        ref = ref + rowv[2].view(B, cout, 1, 1)
+    ref_h = ref.half().float()
+    ref_n = F.group_norm(ref_h, 32, gamma, beta, 1e-5)
+    if silu:
+        ref_n = F.silu(ref_n)
+    y = torch.zeros(B, H, W, cout, device=DEV, dtype=torch.float16)
+    yn = torch.zeros(B, H, W, cout, device=DEV, dtype=torch.float16)
+    d = make_desc(ctx, nhwc16(x), w, b, y, residual=resid, rowvec=rowv, rv_bs=cout, rv_ss=B * cout, step=step)
+    d.gn_groups = 32
+    d.gno_gamma, d.gno_beta, d.gno_eps, d.gno_silu = gamma.data_ptr(), beta.data_ptr(), 1e-5, int(silu)
+    d.gno_y, d.gno_ld, d.gno_skip_y = yn.data_ptr(), cout, int(skip_y)
+    cpg = cout // 32
+    try:
+        ctx.conv_override(-1, sk)
+        if cpg % 4 or H * W * cpg // 4 > 512:
+            assert ctx.conv_gn_fused(d)[0] == 0
+            ctx.conv(d)
+            torch.cuda.synchronize()
+            check(y.permute(0, 3, 1, 2), ref_h)
+            assert not yn.any()
+            return
+        assert ctx.conv_gn_fused(d)[0] == 3
+        ctx.conv(d)
+        torch.cuda.synchronize()
+        check(yn.permute(0, 3, 1, 2), ref_n)
+        if skip_y:
+            assert not y.any()
+        else:
+            check(y.permute(0, 3, 1, 2), ref_h)
+        first = yn.clone()
+        ctx.conv(d)
+        torch.cuda.synchronize()
+        assert torch.equal(first, yn)  # fixed-order reduction: bitwise reproducible
+        ctx.conv_override(-1, 1)
+        assert ctx.conv_gn_fused(d)[0] == 0
+    finally:
+        ctx.conv_override(-1, 0)

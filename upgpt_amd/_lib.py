@@ -64,6 +64,8 @@ class ConvDesc(C.Structure):
         ("gni_mode", C.c_int32), ("gni_silu", C.c_int32), ("gni_groups", C.c_int32), ("gni_eps", C.c_float),
         ("gni_gamma", C.c_void_p), ("gni_beta", C.c_void_p), ("gni_stats1", C.c_void_p), ("gni_stats2", C.c_void_p),
         ("gni_nblk1", C.c_int32), ("gni_ld1", C.c_int32), ("gni_nblk2", C.c_int32), ("gni_ld2", C.c_int32),
+        ("gno_gamma", C.c_void_p), ("gno_beta", C.c_void_p), ("gno_y", C.c_void_p), ("gno_eps", C.c_float),
+        ("gno_silu", C.c_int32), ("gno_ld", C.c_int32), ("gno_skip_y", C.c_int32),
     ]
 
 

@@ -748,6 +748,143 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmArgs a, in
              Epi::fetch(b, rc, n));
 }
 
+// Split-K second pass that applies the GroupNorm (+ SiLU) of what it reduces (include/upk.h gno_*): one workgroup per
+// (sample, group).  A thread owns up to NV vectors of V consecutive channels of the group; every slab load of a
+// vector is issued before the first use, the reduced + fp16-rounded values stay in registers across the group
+// reduction (fp64, fixed order), and the normalised tensor is written from them: the partials are read once and the
+// GroupNorm launch behind a split-K conv disappears.
+struct GnApply {
+  const float* gamma;
+  const float* beta;
+  f16* yn;
+  float eps;
+  int ldn, silu, skip_y, cpg, hw;
+};
+
+template <int V>
+struct VecIO {
+  static __device__ __forceinline__ void ldf(const float* p, bool on, float (&o)[V]) {
+    if constexpr (V == 4) {
+      const f32x4 w = on ? *(const f32x4*)p : (f32x4){0.f, 0.f, 0.f, 0.f};
+      o[0] = w[0], o[1] = w[1], o[2] = w[2], o[3] = w[3];
+    } else if constexpr (V == 2) {
+      const f32x2 w = on ? *(const f32x2*)p : (f32x2){0.f, 0.f};
+      o[0] = w[0], o[1] = w[1];
+    } else {
+      o[0] = on ? *p : 0.f;
+    }
+  }
+  static __device__ __forceinline__ void ldh(const f16* p, bool on, float (&o)[V]) {
+    if constexpr (V == 4) {
+      const f16x4 w = on ? *(const f16x4*)p : (f16x4){0, 0, 0, 0};
+      o[0] = (float)w[0], o[1] = (float)w[1], o[2] = (float)w[2], o[3] = (float)w[3];
+    } else if constexpr (V == 2) {
+      const f16x2 w = on ? *(const f16x2*)p : (f16x2){0, 0};
+      o[0] = (float)w[0], o[1] = (float)w[1];
+    } else {
+      o[0] = on ? (float)*p : 0.f;
+    }
+  }
+  static __device__ __forceinline__ void sth(f16* p, const f16 (&v)[V]) {
+    if constexpr (V == 4) {
+      *(f16x4*)p = (f16x4){v[0], v[1], v[2], v[3]};
+    } else if constexpr (V == 2) {
+      *(f16x2*)p = (f16x2){v[0], v[1]};
+    } else {
+      *p = v[0];
+    }
+  }
+};
+
+template <int V, int NV>
+__global__ __launch_bounds__(256) void igemm_reduce_gnapply_kernel(const IgemmArgs a, int splitk, const GnApply g) {
+  using IO = VecIO<V>;
+  __shared__ double red[8];
+  const int grp = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int vpr = g.cpg / V;
+  const int nvec = g.hw * vpr;
+  const int c0 = grp * g.cpg;
+  const long slab = (long)a.M * a.npad;
+  const int st = (a.rowvec && a.step) ? *a.step : 0;
+  const float* rvb = a.rowvec ? a.rowvec + (unsigned)(st * a.rv_ss + b * a.rv_bs) : nullptr;
+  float h[NV][V], ga[NV][V], be[NV][V];
+  int mrow[NV], ncol[NV];
+  float s = 0.f, ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = tid + k * 256;
+    const bool on = i < nvec;
+    const int p = on ? i / vpr : 0;
+    const int n = c0 + (on ? i - p * vpr : 0) * V;
+    const int m = b * g.hw + p;
+    mrow[k] = on ? m : -1;
+    ncol[k] = n;
+    const float* pp = a.partial + (long)m * a.npad + n;
+    float acc[V], cb[V], cr[V], cs[V];
+    IO::ldf(g.gamma + n, on, ga[k]);  // (not needed before the group reduction: in flight with the slabs)
+    IO::ldf(g.beta + n, on, be[k]);
+    IO::ldf(a.bias + n, on && a.bias != nullptr, cb);
+    IO::ldf(rvb + n, on && rvb != nullptr, cr);
+    IO::ldh(a.res + (long)m * a.ldr + n, on && a.res != nullptr, cs);
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    for (int z0 = 0; z0 < splitk; z0 += 4) {
+      float t[4][V];
+#pragma unroll
+      for (int zz = 0; zz < 4; ++zz) {
+        const bool zon = on && z0 + zz < splitk;
+        IO::ldf(pp + (long)(zon ? z0 + zz : 0) * slab, zon, t[zz]);
+      }
+#pragma unroll
+      for (int zz = 0; zz < 4; ++zz)
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += t[zz][j];
+    }
+    f16 o[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      o[j] = (f16)(acc[j] + (cb[j] + cr[j]) + cs[j]);
+      const float f = (float)o[j];
+      h[k][j] = f;
+      s += f;
+      ss += f * f;
+    }
+    if (on && !g.skip_y) IO::sth((f16*)a.y + (long)m * a.ldy + n, o);
+  }
+  double ds = (double)s, dss = (double)ss;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    ds += __shfl_xor(ds, o);
+    dss += __shfl_xor(dss, o);
+  }
+  if ((tid & 63) == 0) {
+    red[(tid >> 6) * 2] = ds;
+    red[(tid >> 6) * 2 + 1] = dss;
+  }
+  __syncthreads();
+  const double n_el = (double)g.hw * g.cpg;
+  const double mean = (((red[0] + red[2]) + red[4]) + red[6]) / n_el;
+  double var = (((red[1] + red[3]) + red[5]) + red[7]) / n_el - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)g.eps));
+  const float fmean = (float)mean;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const bool on = mrow[k] >= 0;
+    const int n = ncol[k];
+    f16 o[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float sc = rstd * ga[k][j];
+      const float sh = be[k][j] - fmean * sc;
+      float f = h[k][j] * sc + sh;
+      if (g.silu) f = upk_silu(f);
+      o[j] = (f16)f;
+    }
+    if (on) IO::sth(g.yn + (long)mrow[k] * g.ldn + n, o);
+  }
+}
+
 // Split-K second pass that also takes the GroupNorm statistics of what it writes: grid (chunks, B) and
 // thread layout of gn_stats_kernel (norm.hip) — a thread owns 8 consecutive channels, `rpi` pixels in
 // flight — so the partial sums come out in upk_groupnorm's workspace layout and the GroupNorm that
@@ -1093,7 +1230,22 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   const int zdim = cdiv(a.nchunks, a.chunks_per_split);
   a.partial = (zdim > 1) ? (float*)ctx->ws : nullptr;
   // GroupNorm partials from the reduce pass (see igemm_reduce_gn_kernel)
-  const bool gn_fuse = d->gn_stats_ws && zdim > 1 && Epi::plain(a) && !(a.n_out & 7) && a.n_out <= 2048 &&
+  // ... or the whole GroupNorm from the reduce pass (igemm_reduce_gnapply_kernel)
+  int ga_v = 0, ga_nv = 0;
+  if (d->gno_y && zdim > 1 && Epi::plain(a) && d->gn_groups > 0 && a.n_out % d->gn_groups == 0 && d->gno_gamma &&
+      d->gno_beta) {
+    const int cpg = a.n_out / d->gn_groups;
+    // one workgroup per (sample, group) pays while a thread holds <= 2 vectors of 4 channels (the 4x4 / 8x8 levels:
+    // 5.7 / 8.5 us against 6 + 6.5 us for reduce + GroupNorm launch); measured at 16x16 (2-wide vectors, 7 per thread)
+    // 14 us and at 32x32 (scalars, 28 per thread) 36 us — those keep the statistics by-product + apply launch
+    const int v = !(cpg & 3) && !(a.ldy & 3) && !(d->gno_ld & 3) && (!a.res || !(a.ldr & 3)) ? 4 : (!(cpg & 1) ? 2 : 1);
+    const long nvec = (long)a.Ho * a.Wo * (cpg / v);
+    const int nv = (int)((nvec + 255) / 256);
+    static const int nv_max = getenv("UPK_GNAPPLY_NVMAX") ? atoi(getenv("UPK_GNAPPLY_NVMAX")) : 2;
+    if (nv <= (v == 4 ? nv_max : (nv_max > 2 ? (v == 1 ? 32 : 8) : 0))) ga_v = v, ga_nv = nv;
+  }
+  const bool gn_apply = ga_v != 0;
+  const bool gn_fuse = !gn_apply && d->gn_stats_ws && zdim > 1 && Epi::plain(a) && !(a.n_out & 7) && a.n_out <= 2048 &&
                        d->gn_groups > 0 && d->gn_groups <= UPK_GN_GROUPS_MAX && a.n_out % d->gn_groups == 0 &&
                        !(a.ldy & 7) && (!a.res || !(a.ldr & 7));
   // ... or, without split-K, per-(M tile, channel) partials from the plain epilogue (Epi::tile_plain_cp and the
@@ -1107,7 +1259,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     a.gn_nblk = hw_out / BM;
     a.gn_hw = hw_out;
   }
-  if (gn_fused) *gn_fused = gn_fuse ? 1 : (gn_cp ? 2 : 0);
+  if (gn_fused) *gn_fused = gn_apply ? 3 : (gn_fuse ? 1 : (gn_cp ? 2 : 0));
   if (gn_nblk) *gn_nblk = gn_cp ? a.gn_nblk : 0;
   if (!launch) return UPK_OK;
 
@@ -1131,7 +1283,30 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   hipLaunchKernelGGL(a.ln_u ? c.fn_ln : (a.x3 ? c.fn_app : c.fn), grid, dim3(c.nbuf ? 512 : c.wm * c.wn * 64), 0, stream, a);
   int rc = upk_check_launch(ctx, "igemm");
   if (rc) return rc;
-  if (zdim > 1 && gn_fuse) {
+  if (zdim > 1 && gn_apply) {
+    GnApply g;
+    g.gamma = d->gno_gamma;
+    g.beta = d->gno_beta;
+    g.yn = (f16*)d->gno_y;
+    g.eps = d->gno_eps;
+    g.ldn = d->gno_ld;
+    g.silu = d->gno_silu;
+    g.skip_y = d->gno_skip_y;
+    g.cpg = a.n_out / d->gn_groups;
+    g.hw = a.Ho * a.Wo;
+    const dim3 gg(d->gn_groups, a.B);
+    if (ga_v == 4 && ga_nv <= 1)
+      hipLaunchKernelGGL((igemm_reduce_gnapply_kernel<4, 1>), gg, dim3(256), 0, stream, a, zdim, g);
+    else if (ga_v == 4 && ga_nv <= 2)
+      hipLaunchKernelGGL((igemm_reduce_gnapply_kernel<4, 2>), gg, dim3(256), 0, stream, a, zdim, g);
+    else if (ga_v == 4)
+      hipLaunchKernelGGL((igemm_reduce_gnapply_kernel<4, 8>), gg, dim3(256), 0, stream, a, zdim, g);
+    else if (ga_v == 2)
+      hipLaunchKernelGGL((igemm_reduce_gnapply_kernel<2, 8>), gg, dim3(256), 0, stream, a, zdim, g);
+    else
+      hipLaunchKernelGGL((igemm_reduce_gnapply_kernel<1, 32>), gg, dim3(256), 0, stream, a, zdim, g);
+    rc = upk_check_launch(ctx, "igemm_reduce_gnapply");
+  } else if (zdim > 1 && gn_fuse) {
     GnFuse gf;
     gf.ws = d->gn_stats_ws;
     gf.groups = d->gn_groups;

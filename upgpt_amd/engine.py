@@ -67,6 +67,7 @@ TUNE_CACHE = TuneCache(os.environ.get("UPGPT_TUNE_FILE") or None)
 # Off by default: parity-green, but inside the replayed forward it does not beat implicit GEMM + GroupNorm launch yet
 # (profiles/r02_pconv_*): 3.61 ms vs 3.52 ms per forward with the "auto" rule below.
 PCONV_MODE = os.environ.get("UPGPT_PCONV", "0")
+GN_REDUCE_APPLY = os.environ.get("UPGPT_GN_REDUCE_APPLY", "1") == "1"
 PCONV_ON = PCONV_MODE != "0"
 LN_LAUNCH_US = 3.0  # what a separate LayerNorm launch costs inside the replayed forward (class ablation: 3.8)
 
@@ -376,7 +377,7 @@ class Emitter:
                       out=out, vt=vt, nchw_out=nchw_out, out_f32=out_f32, spatial=spatial, ln_eps=ln_eps,
                       gn_stats=gn_stats, append=append)
         if gn is not None and not PCONV_ON:
-            return self.conv(P, self.groupnorm(P, x1, gn[0], gn[1], gn[2], gn[3], gn[4], x2=x2), pw, **kw_all)
+            return self.conv(P, self.groupnorm(P, x1, *gn[:5], x2=x2, sole=len(gn) > 5 and gn[5]), pw, **kw_all)
         ups = bool(flags & L.F_UPSAMPLE2X)
         HL, WL = (2 * H, 2 * W) if ups else (H, W)
         if flags & L.F_PAD_ASYM:
@@ -463,7 +464,7 @@ class Emitter:
         if gn is not None and not use_pc:  # outside the patch kernel's domain: GroupNorm launch + plain conv
             if out_mine:
                 self.bufs.pop()  # (the output buffer allocated above is re-made by the plain call)
-            return self.conv(P, self.groupnorm(P, x1, gn[0], gn[1], gn[2], gn[3], gn[4], x2=x2), pw, **kw_all)
+            return self.conv(P, self.groupnorm(P, x1, *gn[:5], x2=x2, sole=len(gn) > 5 and gn[5]), pw, **kw_all)
         key = self.conv_key(M, pw.n_pad, d.c1, d.c2, ks, stride, flags, residual is not None, rowvec is not None,
                             vt is not None, ln_eps is not None, ka=d.c3 + d.c4)
         if use_pc:
@@ -475,7 +476,7 @@ class Emitter:
         if gn is None:
             P.add(lambda s: chk(fn(h, ref, s)), *keep, cls="igemm_k%d" % ks, label=key)
         else:
-            gamma, beta, eps, silu, ws = gn
+            gamma, beta, eps, silu, ws = gn[:5]
             assert x1.C == d.c1 and (x2 is None or x2.C == d.c2), "fused GroupNorm needs channel counts that are multiples of 32"
             d.gni_gamma, d.gni_beta, d.gni_eps = gamma.data_ptr(), beta.data_ptr(), float(eps)
             d.gni_silu, d.gni_groups = int(bool(silu)), 32
@@ -539,7 +540,8 @@ class Emitter:
             armed.append((d, act.gn_src[2]))
         return armed
 
-    def groupnorm(self, P, x1, gamma, beta, eps, silu, ws, x2=None):
+    def groupnorm(self, P, x1, gamma, beta, eps, silu, ws, x2=None, sole=False):
+        """sole: nothing but this GroupNorm reads x1 (its producer may then skip writing it, see gno_skip_y)."""
         Cc = x1.C + (x2.C if x2 is not None else 0)
         y = Act(self.alloc(x1.M, Cc), x1.B, x1.H, x1.W, Cc)
         fn, h, chk = self.lib.upk_groupnorm_nhwc_f16, self.hctx, self._chk
@@ -556,13 +558,21 @@ class Emitter:
             # unsplit epilogue (every source of a concat must have them); decided by the tuned / cost-model choice
             # at the time the program runs or is captured
             fused_fn, apply_fn = self.lib.upk_conv_gn_fused, self.lib.upk_groupnorm_apply_nhwc_f16
+            mine = None
+            if GN_REDUCE_APPLY and x2 is None and not armed[0][0].gno_y:
+                # a producer that splits K normalises in its reduce pass (include/upk.h gno_*): this op then launches nothing
+                mine = armed[0][0]
+                mine.gno_gamma, mine.gno_beta, mine.gno_eps = gamma.data_ptr(), beta.data_ptr(), float(eps)
+                mine.gno_silu, mine.gno_y, mine.gno_ld, mine.gno_skip_y = int(bool(silu)), y.t.data_ptr(), y.ld, int(bool(sole))
 
             def run(s):
                 info = []
                 for d, sws in armed:
                     mode, nblk = C.c_int(0), C.c_int(0)
                     chk(fused_fn(h, C.byref(d), C.byref(mode), C.byref(nblk)))
-                    info.append((mode.value, nblk.value, d.n_pad, sws.data_ptr()))
+                    info.append((mode.value if mode.value != 3 or d is mine else 0, nblk.value, d.n_pad, sws.data_ptr()))
+                if len(info) == 1 and info[0][0] == 3:
+                    return
                 if len(info) == 1 and info[0][0]:
                     m, nb, ld, p1 = info[0]
                     chk(apply_fn(h, *a, p1, m, nb, ld, None, 0, 0, s))
@@ -743,7 +753,7 @@ class UNetPlan(Emitter):
         g1, b1 = v[n + ".in_layers.0"]
         hh = self.conv(P, x, w[n + ".in_layers.2"], x2=skip, gn=(g1, b1, 1e-5, True, self.gn_ws), gn_stats=True,
                        **self._rv(n))
-        gn2 = (*v[n + ".out_layers.0"], 1e-5, True, self.gn_ws)
+        gn2 = (*v[n + ".out_layers.0"], 1e-5, True, self.gn_ws, True)  # (hh has no reader but this GroupNorm)
         if Lr.cin != Lr.cout:
             if self.fold_skip(hh, w[n + ".out_layers.3"], w[n + ".skip_connection"], x, skip):
                 # skip projection as an appended K segment of the second conv: one launch, no residual round trip
