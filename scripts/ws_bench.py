@@ -1,0 +1,91 @@
+"""Weight-streaming check of the implicit-GEMM kernels on the deep UNet levels (dev tool): every (tile config, split-K)
+under graph replay, with the weights (a) the same buffer every launch (Infinity-Cache warm) and (b) cycling through
+>= 600 MB of copies (HBM cold, as inside the forward).
+
+  python scripts/ws_bench.py [shape-name ...]
+"""
+import ctypes as C
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from upgpt_amd import _lib as L
+from upgpt_amd._lib import get_context
+
+DEV = "cuda"
+# name: (ks, cin, cout, H, W, flags)
+SHAPES = {
+    "ff1_M512": (1, 896, 7168, 8, 8, L.F_GEGLU), "qkv_M512": (1, 896, 3072, 8, 8, 0), "ff2_M512": (1, 3584, 896, 8, 8, 0),
+    "c3_M512": (3, 896, 896, 8, 8, 0), "c3_M128": (3, 896, 896, 4, 4, 0), "k1_M512": (1, 896, 896, 8, 8, 0),
+    "ff1_M2048": (1, 448, 3584, 16, 16, L.F_GEGLU), "c3_M2048": (3, 448, 448, 16, 16, 0),
+}
+
+
+def main():
+    ctx = get_context(0)
+    names = [a for a in sys.argv[1:] if a in SHAPES] or list(SHAPES)
+    B, reps = 8, 16
+    ncfg = ctx.lib.upk_conv_num_configs()
+    for name in names:
+        ks, cin, cout, H, W, flags = SHAPES[name]
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(B, H, W, cin, generator=g).half().to(DEV)
+        K = ks * ks * cin
+        wbytes = K * cout * 2
+        w = (torch.randn(cout, cin, ks, ks, generator=g) / math.sqrt(K)).to(DEV)
+        wp, n_pad = ctx.pack_weight(w.contiguous())
+        ncold = max(2, int(600e6 // wbytes))
+        wps = [wp.clone() for _ in range(ncold)]
+        n_real = cout // 2 if flags & L.F_GEGLU else cout
+        y = torch.zeros(B, H, W, n_real, device=DEV, dtype=torch.float16)
+        bias = torch.zeros(n_pad, device=DEV)
+        gf = 2.0 * B * H * W * cout * K / 1e9
+        print("== %s: k%d %d -> %d @%dx%d M=%d  %.2f GF, weights %.1f MB (cold: %d copies)" % (
+            name, ks, cin, cout, H, W, B * H * W, gf, wbytes / 1e6, ncold), flush=True)
+        res = {}
+        for cfg in range(ncfg):
+            for sk in (1, 2, 4, 8, 9):
+                d = L.ConvDesc()
+                d.x1, d.c1, d.ld1 = x.data_ptr(), cin, cin
+                d.batch, d.in_h, d.in_w, d.ksize, d.stride = B, H, W, ks, 1
+                d.w_packed, d.n_out, d.n_pad, d.bias = wps[0].data_ptr(), cout, n_pad, bias.data_ptr()
+                d.y, d.ldy, d.flags = y.data_ptr(), n_real, flags
+                d.tune_cfg, d.tune_splitk = cfg + 1, sk
+                try:
+                    ctx.conv(d)
+                except L.UpkError:
+                    continue
+                torch.cuda.synchronize()
+                for mode, ncopy in (("warm", 1), ("cold", ncold)):
+                    st = torch.cuda.Stream()
+                    with torch.cuda.stream(st):
+                        ctx.graph_begin()
+                        for r in range(reps):
+                            d.w_packed = wps[r % ncopy].data_ptr()
+                            ctx.conv(d)
+                        gr = ctx.graph_end()
+                        ctx.graph_launch(gr)
+                        st.synchronize()
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        nl = 3 if ncopy == 1 else max(1, ncopy // reps)
+                        for _ in range(nl):
+                            ctx.graph_launch(gr)
+                        e1.record()
+                        st.synchronize()
+                        ctx.graph_destroy(gr)
+                    res.setdefault((cfg, sk), {})[mode] = e0.elapsed_time(e1) * 1e3 / reps / nl
+        rows = sorted(res.items(), key=lambda kv: kv[1]["cold"])
+        for (cfg, sk), t in rows[:8]:
+            print("   cold %6.1f us (%5.2f TB/s w)  warm %6.1f us   cfg %-12s sk %d" % (
+                t["cold"], wbytes / t["cold"] / 1e6, t["warm"], ctx.lib.upk_conv_config_name(cfg).decode(), sk), flush=True)
+        bw = min(res.items(), key=lambda kv: kv[1]["warm"])
+        print("   best warm: %.1f us  cfg %s sk %d (cold %.1f)" % (bw[1]["warm"], ctx.lib.upk_conv_config_name(bw[0][0]).decode(),
+                                                                    bw[0][1], bw[1]["cold"]), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.environ.get("UPK_LIB") or os.path.join(HERE, "libupk.so")  # (UPK_LIB + UPK_CXXFLAGS: dev builds)
 SOURCES = ["igemm.hip", "pconv.hip", "attention.hip", "norm.hip", "misc.hip"]
+# per-file flags.  attention.hip: MFMA results straight into arch VGPRs — the softmax between the two matmuls reads
+# every score with VALU instructions, and with the accumulators in AGPRs 112 of ~600 issue slots per 64-key tile were
+# v_accvgpr moves (the kernels use < 128 registers, there is nothing to gain from the AGPR file)
+FILE_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 ARCH = "gfx950"
 
 
@@ -32,7 +36,7 @@ def _source_hash():
         h.update(os.path.basename(path).encode())
         with open(path, "rb") as f:
             h.update(f.read())
-    h.update((ARCH + " " + os.environ.get("UPK_CXXFLAGS", "")).encode())
+    h.update((ARCH + " " + os.environ.get("UPK_CXXFLAGS", "") + repr(sorted(FILE_FLAGS.items()))).encode())
     return h.hexdigest()
 
 
@@ -62,7 +66,7 @@ def build(force=False, verbose=True):
 
     def cc(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + flags + FILE_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print("[upgpt_amd.build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

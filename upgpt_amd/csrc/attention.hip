@@ -37,11 +37,18 @@ struct AttnArgs {
 // unscaled; softmax uses exp2(s*c - m*c) with c = scale*log2(e) folded into one FMA per
 // score.  V^T fragments are requested before the softmax arithmetic so their latency hides
 // under it.
+// v_exp_f32 as it is: exp2f() wraps it in a range test, two selects and an ldexp so that results below 2^-126 come out
+// as denormals; a softmax weight that small contributes nothing (arguments here are <= 0, -inf for masked keys -> 0),
+// and the softmax is bound by VALU issue (d = 32: 9 of 13 instructions per score were that wrapper and the
+// accumulator moves)
+__device__ __forceinline__ float raw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+#define ATT_ONES ((f16x8){(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f})
+
 template <int D, int QREG, int NS, int QT>
 __device__ __forceinline__ void attn_tile(const AttnArgs& a, const f16* const* qrow, const bool* q_ok,
                                           const f16x8 (*qf)[QREG ? D / 32 : 1], const f16* kbase,
                                           const f16* vbase, int kb, int g, int c, f32x4 (*o)[D / 16], float* mrun,
-                                          float* lrun, int q0) {
+                                          f32x4* lsum, int q0) {
   constexpr int KD = D / 32;
   constexpr int DT = D / 16;
   constexpr int NC = NS / 2;  // 32-key chunks for the PV MFMAs
@@ -104,22 +111,28 @@ __device__ __forceinline__ void attn_tile(const AttnArgs& a, const f16* const* q
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float mnew = fmaxf(mrun[u], mx);  // finite: every tile has >= 1 valid key
-    const float alpha = exp2f((mrun[u] - mnew) * cs);
+    // rescale only when some row's running maximum moved (wave-uniform test; alpha is exactly 1 otherwise): after the
+    // first tiles it rarely does, and the accumulators then stay untouched in their MFMA registers
+    if (__builtin_amdgcn_ballot_w64(mnew != mrun[u]) != 0) {
+      const float alpha = raw_exp2((mrun[u] - mnew) * cs);
+      lsum[u] *= alpha;
+#pragma unroll
+      for (int i = 0; i < DT; ++i) o[u][i] *= alpha;
+    }
     mrun[u] = mnew;
     const float mc = -mnew * cs;
-    float ps = 0.f;
 #pragma unroll
     for (int t = 0; t < NS; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = exp2f(fmaf(s[u][t][r], cs, mc));
-        ps += p;
-        pf[u][t >> 1][(t & 1) * 4 + r] = (f16)p;
-      }
-    lrun[u] = lrun[u] * alpha + ps;
-#pragma unroll
-    for (int i = 0; i < DT; ++i) o[u][i] *= alpha;
+      for (int r = 0; r < 4; ++r) pf[u][t >> 1][(t & 1) * 4 + r] = (f16)raw_exp2(fmaf(s[u][t][r], cs, mc));
   }
+  // softmax denominators on the MFMA pipe: an all-ones V^T fragment makes every row of the product the sum of the
+  // (fp16) weights of the lane's query — no VALU adds, no cross-lane reduction, and numerator and denominator see the
+  // same rounded weights
+#pragma unroll
+  for (int j = 0; j < NC; ++j)
+#pragma unroll
+    for (int u = 0; u < QT; ++u) lsum[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ATT_ONES, pf[u][j], lsum[u], 0, 0, 0);
 #pragma unroll
   for (int i = 0; i < DT; ++i)
 #pragma unroll
@@ -160,7 +173,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   bool q_ok[QT];
   f16x8 qf[QT][QREG ? KD : 1];
   f32x4 o[QT][DT];
-  float mrun[QT], lrun[QT];
+  float mrun[QT];
+  f32x4 lsum[QT];
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
     const int qi = q0 + u * 16 + c;
@@ -173,25 +187,22 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
 #pragma unroll
     for (int i = 0; i < DT; ++i) o[u][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     mrun[u] = -INFINITY;
-    lrun[u] = 0.f;
+    lsum[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
   int kb = 0;
   if (D <= 128) {  // 64-key tiles while they are full; the 32-key form handles the rest
     for (; kb + 64 <= (a.causal ? min(a.nkv, q0 + 16 * QT) : a.nkv); kb += 64)
-      attn_tile<D, QREG, 4, QT>(a, qrow, q_ok, qf, kbase, vbase, kb, g, c, o, mrun, lrun, q0);
+      attn_tile<D, QREG, 4, QT>(a, qrow, q_ok, qf, kbase, vbase, kb, g, c, o, mrun, lsum, q0);
   }
   // causal: keys beyond this wave's last query are never visible (and key 0 always is, so the running max is
   // finite from the first tile on)
   const int kend = a.causal ? min(a.nkv, q0 + 16 * QT) : a.nkv;
-  for (; kb < kend; kb += 32) attn_tile<D, QREG, 2, QT>(a, qrow, q_ok, qf, kbase, vbase, kb, g, c, o, mrun, lrun, q0);
+  for (; kb < kend; kb += 32) attn_tile<D, QREG, 2, QT>(a, qrow, q_ok, qf, kbase, vbase, kb, g, c, o, mrun, lsum, q0);
 
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
-    float l = lrun[u];
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
-    const float inv = 1.0f / l;
+    const float inv = 1.0f / lsum[u][0];
     if (!q_ok[u]) continue;
     f16* orow = a.o + b * a.obs + (long)(q0 + u * 16 + c) * a.ldo + h * D + g * 4;
 #pragma unroll
@@ -234,7 +245,8 @@ __global__ __launch_bounds__(256) void attn_lds_kernel(const AttnArgs a) {
   bool q_ok[QT];
   f16x8 qf[QT][KD];
   f32x4 o[QT][DT];
-  float mrun[QT], lrun[QT];
+  float mrun[QT];
+  f32x4 lsum[QT];
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
     const int qi = q0 + u * 16 + c;
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(256) void attn_lds_kernel(const AttnArgs a) {
 #pragma unroll
     for (int i = 0; i < DT; ++i) o[u][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     mrun[u] = -INFINITY;
-    lrun[u] = 0.f;
+    lsum[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   // staging assignment: K element (kd = it, key = tid>>2, chunk = tid&3); V^T element (row = (tid + 256 it)>>3, col = tid&7)
   const f16* ksrc = a.k + b * a.kbs + (long)(tid >> 2) * a.ldk + h * D + (tid & 3) * 8;
@@ -301,22 +313,23 @@ __global__ __launch_bounds__(256) void attn_lds_kernel(const AttnArgs a) {
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float mnew = fmaxf(mrun[u], mx);
-      const float alpha = exp2f((mrun[u] - mnew) * cs);
+      if (__builtin_amdgcn_ballot_w64(mnew != mrun[u]) != 0) {  // (see attn_tile)
+        const float alpha = raw_exp2((mrun[u] - mnew) * cs);
+        lsum[u] *= alpha;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) o[u][i] *= alpha;
+      }
       mrun[u] = mnew;
       const float mc = -mnew * cs;
-      float ps = 0.f;
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = exp2f(fmaf(sc[u][tt][r], cs, mc));
-          ps += p;
-          pf[u][tt >> 1][(tt & 1) * 4 + r] = (f16)p;
-        }
-      lrun[u] = lrun[u] * alpha + ps;
-#pragma unroll
-      for (int i = 0; i < DT; ++i) o[u][i] *= alpha;
+        for (int r = 0; r < 4; ++r) pf[u][tt >> 1][(tt & 1) * 4 + r] = (f16)raw_exp2(fmaf(sc[u][tt][r], cs, mc));
     }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)  // denominators (see attn_tile)
+#pragma unroll
+      for (int u = 0; u < QT; ++u) lsum[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ATT_ONES, pf[u][j], lsum[u], 0, 0, 0);
     // ---- O^T += V^T P^T ----
 #pragma unroll
     for (int i = 0; i < DT; ++i)
@@ -333,10 +346,7 @@ __global__ __launch_bounds__(256) void attn_lds_kernel(const AttnArgs a) {
   }
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
-    float l = lrun[u];
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
-    const float inv = 1.0f / l;
+    const float inv = 1.0f / lsum[u][0];
     if (!q_ok[u]) continue;
     f16* orow = a.o + b * a.obs + (long)(q0 + u * 16 + c) * a.ldo + h * D + g * 4;
 #pragma unroll
