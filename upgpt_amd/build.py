@@ -17,7 +17,10 @@ SOURCES = ["igemm.hip", "pconv.hip", "attention.hip", "norm.hip", "misc.hip"]
 # per-file flags.  attention.hip: MFMA results straight into arch VGPRs — the softmax between the two matmuls reads
 # every score with VALU instructions, and with the accumulators in AGPRs 112 of ~600 issue slots per 64-key tile were
 # v_accvgpr moves (the kernels use < 128 registers, there is nothing to gain from the AGPR file)
-FILE_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# -fno-honor-nans -mno-amdgpu-ieee: fmaxf on MFMA results otherwise quiets every operand first (v_max x, x) — two of
+# three instructions of the running-maximum tree; the kernels never produce a NaN (masked scores are -inf, every tile
+# has a visible key per row, so no inf - inf) and infinities keep their meaning
+FILE_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans", "-mno-amdgpu-ieee"]}
 ARCH = "gfx950"
 
 

@@ -42,6 +42,16 @@ struct AttnArgs {
 // and the softmax is bound by VALU issue (d = 32: 9 of 13 instructions per score were that wrapper and the
 // accumulator moves)
 __device__ __forceinline__ float raw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// max over the four lanes (c, c+16, c+32, c+48) that hold the keys of one query: gfx950's permlane swaps are VALU
+// instructions (2 + 2 issue slots), where __shfl_xor is two dependent LDS-crossbar round trips in the middle of the
+// softmax's critical path
+__device__ __forceinline__ float max_over_key_groups(float x) {
+  unsigned u = __float_as_uint(x);
+  const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  u = __float_as_uint(fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1])));
+  const auto b = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
 #define ATT_ONES ((f16x8){(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f})
 
 template <int D, int QREG, int NS, int QT>
@@ -108,8 +118,7 @@ __device__ __forceinline__ void attn_tile(const AttnArgs& a, const f16* const* q
 #pragma unroll
     for (int t = 0; t < NS; ++t)
       mx = fmaxf(mx, fmaxf(fmaxf(s[u][t][0], s[u][t][1]), fmaxf(s[u][t][2], s[u][t][3])));
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = max_over_key_groups(mx);
     const float mnew = fmaxf(mrun[u], mx);  // finite: every tile has >= 1 valid key
     // rescale only when some row's running maximum moved (wave-uniform test; alpha is exactly 1 otherwise): after the
     // first tiles it rarely does, and the accumulators then stay untouched in their MFMA registers
@@ -310,8 +319,7 @@ __global__ __launch_bounds__(256) void attn_lds_kernel(const AttnArgs a) {
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
         mx = fmaxf(mx, fmaxf(fmaxf(sc[u][tt][0], sc[u][tt][1]), fmaxf(sc[u][tt][2], sc[u][tt][3])));
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mx = max_over_key_groups(mx);
       const float mnew = fmaxf(mrun[u], mx);
       if (__builtin_amdgcn_ballot_w64(mnew != mrun[u]) != 0) {  // (see attn_tile)
         const float alpha = raw_exp2((mrun[u] - mnew) * cs);
@@ -389,7 +397,8 @@ static int attention_impl(upk_ctx* ctx, const void* q, int ldq, long long qbs, c
   a.causal = causal;
   if (causal && n_q != n_kv) return upk_fail(ctx, UPK_EINVAL, "attention: causal needs n_q == n_kv");
   // two 16-query groups per wave when there are enough queries to keep every CU busy
-  const int qt = (d <= 128 && (long)((n_q + 127) / 128) * batch * heads >= 2L * ctx->num_cus) ? 2 : 1;
+  static const int qt_env = getenv("UPK_ATTN_QT") ? atoi(getenv("UPK_ATTN_QT")) : 0;  // dev
+  const int qt = qt_env ? qt_env : ((d <= 128 && (long)((n_q + 127) / 128) * batch * heads >= 2L * ctx->num_cus) ? 2 : 1);
   dim3 grid((n_q + 64 * qt - 1) / (64 * qt), batch * heads), block(256);
   upk_prof_scope prof(ctx, UPK_CLS_ATTN, stream);
   // long self-attention sequences: K / V^T tiles shared through LDS (whole 64-key tiles only)
