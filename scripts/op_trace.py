@@ -37,6 +37,30 @@ def run(H, W, out):
     print("ops per forward:", len(pl.body.ops))
 
 
+def run_vae(H, W, out):
+    """Same for the VAE decoder (latent HxW, B=8)."""
+    import torch
+    import upgpt_amd
+    from upgpt_amd import synth
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = upgpt_amd.build_model("bbox")
+    synth.fill_module_(model); model = model.cuda()
+    vp = model.first_stage_model._decode_plan(8, H, W, 0.18215)
+    vp.z.copy_(torch.randn(8, 4, H, W))
+    ctx = vp.ctx
+    mark = torch.zeros(1, dtype=torch.int32, device="cuda")
+    s = ctx._s()
+    torch.cuda.synchronize()
+    for rep in range(3):
+        ctx.advance_step(mark); ctx.advance_step(mark); ctx.advance_step(mark)
+        for op in vp.prog.ops:
+            op(s)
+            ctx.advance_step(mark)
+        torch.cuda.synchronize()
+    json.dump({"labels": vp.prog.labels, "cls": vp.prog.cls}, open(out, "w"))
+    print("ops per decode:", len(vp.prog.ops))
+
+
 def parse(trace, labels):
     import csv
     L = json.load(open(labels))
@@ -75,6 +99,6 @@ if __name__ == "__main__":
     if sys.argv[1] == "run":
         H = int(sys.argv[2]) if len(sys.argv) > 2 else 32
         W = int(sys.argv[3]) if len(sys.argv) > 3 else 32
-        run(H, W, os.environ.get("OT_LABELS", "gpurun_out/ot_labels.json"))
+        (run_vae if os.environ.get("OT_VAE") else run)(H, W, os.environ.get("OT_LABELS", "gpurun_out/ot_labels.json"))
     else:
         parse(sys.argv[2], sys.argv[3])

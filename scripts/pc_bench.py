@@ -21,6 +21,8 @@ SHAPES = {
     "L1a": (3, 448, 0, 0, 448, 16, 16, 1), "L1c": (3, 896, 448, 0, 448, 16, 16, 1), "L1k": (3, 448, 0, 1344, 448, 16, 16, 1),
     "L2a": (3, 896, 0, 0, 896, 8, 8, 1), "L2c": (3, 896, 896, 0, 896, 8, 8, 1), "L2k": (3, 896, 0, 1792, 896, 8, 8, 1),
     "L3a": (3, 896, 0, 0, 896, 4, 4, 1), "L3c": (3, 896, 896, 0, 896, 4, 4, 1),
+    "V3a": (3, 128, 0, 0, 128, 256, 256, 1), "V2a": (3, 256, 0, 0, 256, 128, 128, 1), "V1a": (3, 512, 0, 0, 512, 64, 64, 1),
+    "V0a": (3, 512, 0, 0, 512, 32, 32, 1),
     "P0": (1, 224, 0, 0, 224, 32, 32, 1), "P2": (1, 896, 0, 0, 896, 8, 8, 1), "L0n": (3, 224, 0, 0, 224, 32, 32, 0),
 }
 
@@ -29,10 +31,11 @@ def main():
     ctx = get_context(0)
     names = [a for a in sys.argv[1:] if a in SHAPES] or list(SHAPES)
     only = [int(v) for v in os.environ.get("UPK_PC_CFGS", "").split(",") if v]
-    B, reps = 8, 20
+    B = 8
     ncfg = ctx.lib.upk_pconv_num_configs()
     for name in names:
         ks, c1, c2, ca, cout, H, W, gn = SHAPES[name]
+        reps = 20 if H * W <= 1024 else 4
         g = torch.Generator().manual_seed(1)
         x1 = torch.randn(B, H, W, c1, generator=g).half().to(DEV)
         x2 = torch.randn(B, H, W, c2, generator=g).half().to(DEV) if c2 else None

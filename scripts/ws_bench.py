@@ -21,16 +21,20 @@ SHAPES = {
     "ff1_M512": (1, 896, 7168, 8, 8, L.F_GEGLU), "qkv_M512": (1, 896, 3072, 8, 8, 0), "ff2_M512": (1, 3584, 896, 8, 8, 0),
     "c3_M512": (3, 896, 896, 8, 8, 0), "c3_M128": (3, 896, 896, 4, 4, 0), "k1_M512": (1, 896, 896, 8, 8, 0),
     "ff1_M2048": (1, 448, 3584, 16, 16, L.F_GEGLU), "c3_M2048": (3, 448, 448, 16, 16, 0),
+    "ff1_M8192": (1, 224, 1792, 32, 32, L.F_GEGLU), "qkv_M8192": (1, 224, 768, 32, 32, 0), "ff2_M8192": (1, 896, 224, 32, 32, 0),
+    "c3_M8192": (3, 224, 224, 32, 32, 0), "k1_M8192": (1, 224, 224, 32, 32, 0), "c3_M8192_448": (3, 448, 224, 32, 32, 0),
 }
 
 
 def main():
     ctx = get_context(0)
-    names = [a for a in sys.argv[1:] if a in SHAPES] or list(SHAPES)
+    names = [a for a in sys.argv[1:] if a.split("+")[0] in SHAPES] or list(SHAPES)  # name[+gs][+rv][+res]
     B, reps = 8, 16
     ncfg = ctx.lib.upk_conv_num_configs()
     for name in names:
-        ks, cin, cout, H, W, flags = SHAPES[name]
+        base = name.split("+")[0]
+        feats = name.split("+")[1:]
+        ks, cin, cout, H, W, flags = SHAPES[base]
         g = torch.Generator().manual_seed(1)
         x = torch.randn(B, H, W, cin, generator=g).half().to(DEV)
         K = ks * ks * cin
@@ -42,6 +46,10 @@ def main():
         n_real = cout // 2 if flags & L.F_GEGLU else cout
         y = torch.zeros(B, H, W, n_real, device=DEV, dtype=torch.float16)
         bias = torch.zeros(n_pad, device=DEV)
+        sws = torch.zeros(ctx.gn_stats_floats(B, n_pad), device=DEV)
+        rowv = torch.zeros(50, n_pad, device=DEV)
+        stepc = torch.zeros(1, dtype=torch.int32, device=DEV)
+        resid = torch.zeros(B, H, W, n_real, device=DEV, dtype=torch.float16)
         gf = 2.0 * B * H * W * cout * K / 1e9
         print("== %s: k%d %d -> %d @%dx%d M=%d  %.2f GF, weights %.1f MB (cold: %d copies)" % (
             name, ks, cin, cout, H, W, B * H * W, gf, wbytes / 1e6, ncold), flush=True)
@@ -54,6 +62,12 @@ def main():
                 d.w_packed, d.n_out, d.n_pad, d.bias = wps[0].data_ptr(), cout, n_pad, bias.data_ptr()
                 d.y, d.ldy, d.flags = y.data_ptr(), n_real, flags
                 d.tune_cfg, d.tune_splitk = cfg + 1, sk
+                if "gs" in feats:
+                    d.gn_stats_ws, d.gn_groups = sws.data_ptr(), 32
+                if "rv" in feats:
+                    d.rowvec, d.rv_batch_stride, d.rv_step_stride, d.step = rowv.data_ptr(), 0, n_pad, stepc.data_ptr()
+                if "res" in feats:
+                    d.residual, d.ld_res = resid.data_ptr(), n_real
                 try:
                     ctx.conv(d)
                 except L.UpkError:

@@ -67,7 +67,23 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a) {
     float s[8], ss[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
-    for (int p = p0 + r; p < p1; p += rpi) {
+    // 8 pixels in flight per thread (a one-load-per-iteration loop runs at the latency of a load: 2 TB/s on the VAE
+    // decoder's 134 MB tensors); the accumulation order per thread stays p0 + r, + rpi, ... -> same sums as before
+    int p = p0 + r;
+    for (; p + 7 * rpi < p1; p += 8 * rpi) {
+      f16x8 xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xv[u] = gn_load(a, (long)b * a.hw + p + u * rpi, v);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = (float)xv[u][j];
+          s[j] += f;
+          ss[j] += f * f;
+        }
+    }
+    for (; p < p1; p += rpi) {
       const f16x8 xv = gn_load(a, (long)b * a.hw + p, v);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -237,9 +253,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a, int rows_
     const int i = tid + k * 256;
     if (i < nvec) emit(i, pre[k]);
   }
-  for (int i = tid + GN_PREF * 256; i < nvec; i += 256) {
-    const int pr = i / vpr;
-    emit(i, gn_load(a, (long)b * a.hw + p0 + pr, i - pr * vpr));
+  for (int base = GN_PREF * 256; base < nvec; base += GN_PREF * 256) {  // (large tensors: GN_PREF loads in flight)
+#pragma unroll
+    for (int k = 0; k < GN_PREF; ++k) {
+      const int i = base + tid + k * 256;
+      if (i < nvec) {
+        const int pr = i / vpr;
+        pre[k] = gn_load(a, (long)b * a.hw + p0 + pr, i - pr * vpr);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < GN_PREF; ++k) {
+      const int i = base + tid + k * 256;
+      if (i < nvec) emit(i, pre[k]);
+    }
   }
 }
 
@@ -364,8 +391,12 @@ static int gn_launch(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* 
   }
   // apply: ~4 KB of fp16 per block (>= 3 blocks per CU on the UNet shapes: the kernel is a chain of
   // dependent memory round trips, so it needs co-resident blocks, not long per-block loops)
+  // ... up to ~4096 blocks: beyond that (VAE decoder: 64 K - 524 K rows) a block's fixed part — folding the partial
+  // statistics, gamma / beta, the scale / shift table — outweighs its 4 KB of data
   int rows = (2048 + C - 1) / C;
   if (rows < 1) rows = 1;
+  const long rows_big = ((long)hw * batch + 4095) / 4096;
+  if (rows_big > rows) rows = (int)(rows_big < 4096 ? rows_big : 4096);
   const int blocks = (hw + rows - 1) / rows;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, batch), dim3(256), (size_t)C * 2 * sizeof(float), stream, a, rows);
   return upk_check_launch(ctx, "gn_apply");
