@@ -255,6 +255,20 @@ int upk_attention_causal_f16(upk_ctx* ctx, const void* q, int ldq, long long q_b
                              void* out, int ldo, long long o_batch_stride, int batch, int heads, int n,
                              int d, float scale, upk_stream stream);
 
+/* Cross-attention with the query projection inside: out = softmax(to_q(LayerNorm(x)) K^T * scale) V —
+ * CrossAttention.forward (attention.py:170-196) behind BasicTransformerBlock.norm2 (attention.py:213), for the
+ * attention whose K / V come from the (step-invariant) context.  x: [batch][n_q][ldx] fp16 un-normalised rows,
+ * cq = 224 * n channels of which the first ln_dim are real.  wq: fp16 [heads][d][cq], W * gamma (LayerNorm affine
+ * folded in), head dim zero-padded to d, the d rows of each head stored in the order
+ *   row (32 kd + 16 t + m)  holds  d = 32 kd + 8 (m >> 2) + 4 t + (m & 3)      (t = 0,1; m = 0..15)
+ * so that the projection's MFMA output is the score MFMA's operand fragment as it stands; wq_colsum / wq_bias:
+ * [heads * d] fp32 in natural d order, column sums of the fp16-rounded wq rows and W beta (+ bias).  d in {32, 64}.
+ * k / vt / out as upk_attention_f16. */
+int upk_attention_qproj_f16(upk_ctx* ctx, const void* x, int ldx, long long xbs, int cq, int ln_dim, float ln_eps,
+                            const void* wq, const float* wq_colsum, const float* wq_bias, const void* k, int ldk,
+                            long long kbs, const void* vt, int vt_ld, void* out, int ldo, long long obs, int batch,
+                            int heads, int n_q, int n_kv, int d, float scale, upk_stream stream);
+
 /* out[r, :] = tok_emb[ids[r], :] + pos_emb[r % seq, :]  (fp16 tables [vocab, dim] / [seq, dim], fp16 out [rows, ld]):
  * CLIPTextEmbeddings.  ids outside [0, vocab) are an error the kernel cannot report: validate on the host. */
 int upk_embed_tokens_f16(upk_ctx* ctx, const int32_t* ids, const void* tok_emb, const void* pos_emb, int rows,

@@ -827,3 +827,37 @@ def test_splitk_reduce_applies_groupnorm(ctx, H, W, cin, cout, ks, sk, res, rv, 
         assert ctx.conv_gn_fused(d)[0] == 0
     finally:
         ctx.conv_override(-1, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,heads,dh,nq,nkv", [(224, 8, 28, 1024, 87), (448, 8, 56, 256, 87), (224, 8, 28, 768, 87),
+                                                (448, 7, 64, 192, 77), (224, 7, 32, 100, 33)])
+def test_attention_with_query_projection_inside(ctx, C, heads, dh, nq, nkv):
+    """upk_attention_qproj_f16 = LayerNorm -> to_q -> cross-attention (attention.py:170-196 behind :213) against the
+    same three steps in plain PyTorch (q rounded to fp16 as the unfused path's GEMM output is)."""
+    from upgpt_amd.engine import head_pad, qproj_pack
+    B = 2
+    dp = head_pad(dh)
+    x = (rnd(B, nq, C) * 1.5 + 0.2).half()
+    w = rnd(heads * dh, C, seed=1, scale=1 / math.sqrt(C))
+    gamma, beta = 1 + 0.2 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    k = torch.zeros(B, nkv, heads * dp, device=DEV, dtype=torch.float16)
+    k.view(B, nkv, heads, dp)[..., :dh] = rnd(B, nkv, heads, dh, seed=4).half()
+    v = rnd(B, nkv, heads, dh, seed=5).half()
+    vt_ld = (nkv + 31) // 32 * 32
+    vt = torch.zeros(B, heads, dp, vt_ld, device=DEV, dtype=torch.float16)
+    vt[:, :, :dh, :nkv] = v.permute(0, 2, 3, 1)
+    scale = dh ** -0.5
+    wq, wu, wb = qproj_pack(w, gamma, beta, heads, dh, dp, C, DEV)
+    out = torch.zeros(B, nq, heads * dp, device=DEV, dtype=torch.float16)
+    ctx._chk(ctx.lib.upk_attention_qproj_f16(ctx.h, x.data_ptr(), C, nq * C, C, C, 1e-5, wq.data_ptr(), wu.data_ptr(),
+                                             wb.data_ptr(), k.data_ptr(), heads * dp, nkv * heads * dp, vt.data_ptr(),
+                                             vt_ld, out.data_ptr(), heads * dp, nq * heads * dp, B, heads, nq, nkv, dp,
+                                             scale, ctx._s()))
+    torch.cuda.synchronize()
+    q = F.linear(F.layer_norm(x.float(), (C,), gamma, beta, 1e-5), w).half().float().view(B, nq, heads, dh).transpose(1, 2)
+    kf = k.view(B, nkv, heads, dp)[..., :dh].float().transpose(1, 2)
+    ref = torch.softmax(q @ kf.transpose(-1, -2) * scale, -1) @ v.float().transpose(1, 2)
+    got = out.view(B, nq, heads, dp)[..., :dh].transpose(1, 2)
+    check(got, ref, tol=1e-2)
+    assert not out.view(B, nq, heads, dp)[..., dh:].any()  # the padded head columns stay zero

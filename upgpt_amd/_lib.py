@@ -22,7 +22,7 @@ SYMBOLS = [
     "upk_attention_f16", "upk_groupnorm_nhwc_f16", "upk_groupnorm_stats_nhwc_f16", "upk_groupnorm_chunks", "upk_groupnorm_apply_nhwc_f16", "upk_groupnorm_ws_bytes",
     "upk_layernorm_f16", "upk_timestep_embed_f16",
     "upk_nchw_f32_to_nhwc_f16", "upk_nhwc_f16_to_nchw_f32", "upk_f32_to_f16", "upk_ddim_step_f32",
-    "upk_ddim_step_cfg_f32", "upk_plms_step_f32", "upk_attention_causal_f16", "upk_embed_tokens_f16",
+    "upk_ddim_step_cfg_f32", "upk_plms_step_f32", "upk_attention_causal_f16", "upk_attention_qproj_f16", "upk_embed_tokens_f16",
     "upk_patchify_nchw_f32_f16", "upk_vit_assemble_f16", "upk_gather_rows_f16",
     "upk_advance_step", "upk_step_autoadvance", "upk_kernel_launches", "upk_graph_begin", "upk_graph_end", "upk_graph_launch", "upk_graph_destroy",
     "upk_prof_enable", "upk_prof_collect",
@@ -109,6 +109,8 @@ def load_library(path=None):
                                             i32, i32, i32, i32, i32, f32, vp]),
             "upk_attention_causal_f16": (C.c_int, [vp, vp, i32, i64, vp, i32, i64, vp, i32, vp, i32, i64,
                                                    i32, i32, i32, i32, f32, vp]),
+            "upk_attention_qproj_f16": (C.c_int, [vp, vp, i32, i64, i32, i32, f32, vp, vp, vp, vp, i32, i64, vp, i32, vp,
+                                                  i32, i64, i32, i32, i32, i32, i32, f32, vp]),
             "upk_embed_tokens_f16": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
             "upk_gather_rows_f16": (C.c_int, [vp, vp, i32, vp, i32, i32, i32, vp, i32, vp]),
             "upk_patchify_nchw_f32_f16": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp, i32, vp]),

@@ -52,6 +52,14 @@ __device__ __forceinline__ float max_over_key_groups(float x) {
   const auto b = __builtin_amdgcn_permlane16_swap(u, u, false, false);
   return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
+// sum over the four lanes (c, c+16, c+32, c+48) (see max_over_key_groups)
+__device__ __forceinline__ float sum_over_key_groups(float x) {
+  unsigned u = __float_as_uint(x);
+  const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  u = __float_as_uint(__uint_as_float(a[0]) + __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 #define ATT_ONES ((f16x8){(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f})
 
 template <int D, int QREG, int NS, int QT>
@@ -209,6 +217,137 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   const int kend = a.causal ? min(a.nkv, q0 + 16 * QT) : a.nkv;
   for (; kb < kend; kb += 32) attn_tile<D, QREG, 2, QT>(a, qrow, q_ok, qf, kbase, vbase, kb, g, c, o, mrun, lsum, q0);
 
+#pragma unroll
+  for (int u = 0; u < QT; ++u) {
+    const float inv = 1.0f / lsum[u][0];
+    if (!q_ok[u]) continue;
+    f16* orow = a.o + b * a.obs + (long)(q0 + u * 16 + c) * a.ldo + h * D + g * 4;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) {
+      f16x4 ov;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ov[r] = (f16)(o[u][i][r] * inv);
+      *(f16x4*)(orow + i * 16) = ov;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Cross-attention with its query projection inside (CrossAttention.forward, attention.py:170-196, behind
+// BasicTransformerBlock.norm2, attention.py:213): q = to_q(LayerNorm(x)) is consumed by nothing but this attention,
+// and per head it is a [d x C] slice of the weight — 14 KB at the 32x32 level — against a GEMM launch of its own
+// (8-10 us under replay) plus a write and a read of q.  A wave projects the QT*16 rows it owns:
+//   q^T[d][row] = sum_c W'[d][c] x[row][c]      A operand = rows of W' (gamma folded in), B operand = x rows
+// with the LayerNorm folded the way igemm's ln_colsum does it: q = rstd * (acc - mean * colsum(W')) + W beta, the row
+// sums taken from the x fragments the lane loads anyway.  The host stores W' with its rows permuted so that the two
+// 16-row output tiles of a 32-wide d chunk leave lane (g, c) with d = 32 kd + 8 g + 0..7 of row c — exactly the
+// B-operand fragment of the S^T = K Q^T MFMA: no cross-lane movement, K stays as it is.
+struct QProj {
+  const f16* x;      // [B][nq][ldx] un-normalised rows
+  const f16* w;      // [heads][D (row-permuted)][cq] fp16, LayerNorm gamma folded in
+  const float* u;    // [heads * D] column sums of the fp16-rounded W' (natural d order)
+  const float* bias; // [heads * D] W beta (+ the Linear's bias) (natural d order)
+  long xbs;
+  int ldx, cq, ln_dim;
+  float eps;
+};
+
+template <int D, int QT>
+__global__ __launch_bounds__(256) void attn_qproj_kernel(const AttnArgs a, const QProj p) {
+  constexpr int KD = D / 32;
+  constexpr int DT = D / 16;
+  constexpr int KC = 7;  // x / W' chunks in flight per batch (C = 224 * n)
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int bh = blockIdx.y;
+  const int b = bh / a.heads;
+  const int h = bh - b * a.heads;
+  const int q0 = (blockIdx.x * 4 + wave) * 16 * QT;
+  if (q0 >= a.nq) return;
+  const f16* kbase = a.k + b * a.kbs + h * D + g * 8;
+  const f16* vbase = a.vt + ((long)(b * a.heads + h) * D + c) * a.vt_ld + g * 4;
+
+  const f16* qrow[QT];  // (unused by attn_tile with QREG = 1)
+  bool q_ok[QT];
+  f16x8 qf[QT][KD];
+  f32x4 o[QT][DT];
+  float mrun[QT];
+  f32x4 lsum[QT];
+  {
+    f32x4 qa[QT][DT];
+    float s1[QT], s2[QT];
+    const f16* xr[QT];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+      const int qi = q0 + u * 16 + c;
+      q_ok[u] = qi < a.nq;
+      qrow[u] = nullptr;
+      xr[u] = p.x + b * p.xbs + (long)(q_ok[u] ? qi : 0) * p.ldx + g * 8;
+      s1[u] = s2[u] = 0.f;
+#pragma unroll
+      for (int i = 0; i < DT; ++i) qa[u][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const f16* wr = p.w + (long)(h * D + c) * p.cq + g * 8;
+    const long wtile = (long)16 * p.cq;
+    const f16x2 one2 = {(f16)1.f, (f16)1.f};
+    for (int k0 = 0; k0 < p.cq; k0 += KC * 32) {
+      f16x8 xv[QT][KC], wv[DT][KC];
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+        for (int u = 0; u < QT; ++u) xv[u][kc] = *(const f16x8*)(xr[u] + k0 + kc * 32);
+#pragma unroll
+        for (int i = 0; i < DT; ++i) wv[i][kc] = *(const f16x8*)(wr + i * wtile + k0 + kc * 32);
+      }
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+        for (int u = 0; u < QT; ++u) {
+#pragma unroll
+          for (int hh = 0; hh < 4; ++hh) {
+            const f16x2 xx = {xv[u][kc][2 * hh], xv[u][kc][2 * hh + 1]};
+            s1[u] = __builtin_amdgcn_fdot2(xx, one2, s1[u], false);
+            s2[u] = __builtin_amdgcn_fdot2(xx, xx, s2[u], false);
+          }
+#pragma unroll
+          for (int i = 0; i < DT; ++i)
+            qa[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][kc], xv[u][kc], qa[u][i], 0, 0, 0);
+        }
+      }
+    }
+    const float inv_dim = 1.0f / (float)p.ln_dim;
+    float mean[QT], rstd[QT];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+      const float t1 = sum_over_key_groups(s1[u]), t2 = sum_over_key_groups(s2[u]);
+      mean[u] = t1 * inv_dim;
+      rstd[u] = rsqrtf(fmaxf(t2 * inv_dim - mean[u] * mean[u], 0.f) + p.eps);
+    }
+#pragma unroll
+    for (int kd = 0; kd < KD; ++kd) {
+      const int d0 = h * D + kd * 32 + g * 8;
+      const f32x4 u0 = *(const f32x4*)(p.u + d0), u1 = *(const f32x4*)(p.u + d0 + 4);
+      const f32x4 b0 = *(const f32x4*)(p.bias + d0), b1 = *(const f32x4*)(p.bias + d0 + 4);
+#pragma unroll
+      for (int u = 0; u < QT; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          qf[u][kd][r] = (f16)((qa[u][2 * kd][r] - mean[u] * u0[r]) * rstd[u] + b0[r]);
+          qf[u][kd][4 + r] = (f16)((qa[u][2 * kd + 1][r] - mean[u] * u1[r]) * rstd[u] + b1[r]);
+        }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < QT; ++u) {
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[u][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mrun[u] = -INFINITY;
+    lsum[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  int kb = 0;
+  for (; kb + 64 <= a.nkv; kb += 64) attn_tile<D, 1, 4, QT>(a, qrow, q_ok, qf, kbase, vbase, kb, g, c, o, mrun, lsum, q0);
+  for (; kb < a.nkv; kb += 32) attn_tile<D, 1, 2, QT>(a, qrow, q_ok, qf, kbase, vbase, kb, g, c, o, mrun, lsum, q0);
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
     const float inv = 1.0f / lsum[u][0];
@@ -441,4 +580,55 @@ extern "C" int upk_attention_causal_f16(upk_ctx* ctx, const void* q, int ldq, lo
                                         long long kbs, const void* vt, int vt_ld, void* out, int ldo, long long obs,
                                         int batch, int heads, int n, int d, float scale, upk_stream stream) {
   return attention_impl(ctx, q, ldq, qbs, k, ldk, kbs, vt, vt_ld, out, ldo, obs, batch, heads, n, n, d, scale, 1, stream);
+}
+
+extern "C" int upk_attention_qproj_f16(upk_ctx* ctx, const void* x, int ldx, long long xbs, int cq, int ln_dim,
+                                       float ln_eps, const void* wq, const float* wq_colsum, const float* wq_bias,
+                                       const void* k, int ldk, long long kbs, const void* vt, int vt_ld, void* out,
+                                       int ldo, long long obs, int batch, int heads, int n_q, int n_kv, int d,
+                                       float scale, upk_stream stream_) {
+  if (!ctx) return UPK_EINVAL;
+  if (!x || !wq || !wq_colsum || !wq_bias || !k || !vt || !out) return upk_fail(ctx, UPK_EINVAL, "attention_qproj: null pointer");
+  if (batch <= 0 || heads <= 0 || n_q <= 0 || n_kv <= 0) return upk_fail(ctx, UPK_EINVAL, "attention_qproj: empty");
+  if ((ldx & 7) || (ldk & 7) || (vt_ld & 3) || (ldo & 3) || vt_ld < ((n_kv + 31) & ~31))
+    return upk_fail(ctx, UPK_EINVAL, "attention_qproj: ldx/ldk %% 8, vt_ld %% 4 and vt_ld >= round_up(n_kv,32) required");
+  if ((d != 32 && d != 64) || cq <= 0 || cq % 224 || ln_dim <= 0 || ln_dim > cq || ldx < cq)
+    return upk_fail(ctx, UPK_ESHAPE, "attention_qproj: head dim %d / %d input channels outside {32,64} / 224*n", d, cq);
+  hipStream_t stream = (hipStream_t)stream_;
+  AttnArgs a;
+  a.q = nullptr;
+  a.k = (const f16*)k;
+  a.vt = (const f16*)vt;
+  a.o = (f16*)out;
+  a.ldq = 0;
+  a.ldk = ldk;
+  a.vt_ld = vt_ld;
+  a.ldo = ldo;
+  a.qbs = 0;
+  a.kbs = kbs;
+  a.obs = obs;
+  a.heads = heads;
+  a.nq = n_q;
+  a.nkv = n_kv;
+  a.scale_log2 = scale * 1.4426950408889634f;
+  a.causal = 0;
+  QProj p;
+  p.x = (const f16*)x;
+  p.w = (const f16*)wq;
+  p.u = wq_colsum;
+  p.bias = wq_bias;
+  p.xbs = xbs;
+  p.ldx = ldx;
+  p.cq = cq;
+  p.ln_dim = ln_dim;
+  p.eps = ln_eps;
+  upk_prof_scope prof(ctx, UPK_CLS_ATTN, stream);
+  if (d == 32) {
+    dim3 grid((n_q + 127) / 128, batch * heads);
+    hipLaunchKernelGGL((attn_qproj_kernel<32, 2>), grid, dim3(256), 0, stream, a, p);
+  } else {
+    dim3 grid((n_q + 63) / 64, batch * heads);  // (two query groups per wave measured slower: 21.5 vs 17.8 us at 256 x 8 heads)
+    hipLaunchKernelGGL((attn_qproj_kernel<64, 1>), grid, dim3(256), 0, stream, a, p);
+  }
+  return upk_check_launch(ctx, "attention_qproj");
 }

@@ -393,7 +393,8 @@ static int gn_launch(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* 
   // dependent memory round trips, so it needs co-resident blocks, not long per-block loops)
   // ... up to ~4096 blocks: beyond that (VAE decoder: 64 K - 524 K rows) a block's fixed part — folding the partial
   // statistics, gamma / beta, the scale / shift table — outweighs its 4 KB of data
-  int rows = (2048 + C - 1) / C;
+  static const int blk_elems = getenv("UPK_GN_BLOCK_ELEMS") ? atoi(getenv("UPK_GN_BLOCK_ELEMS")) : 2048;  // dev
+  int rows = (blk_elems + C - 1) / C;
   if (rows < 1) rows = 1;
   const long rows_big = ((long)hw * batch + 4095) / 4096;
   if (rows_big > rows) rows = (int)(rows_big < 4096 ? rows_big : 4096);

@@ -67,6 +67,7 @@ TUNE_CACHE = TuneCache(os.environ.get("UPGPT_TUNE_FILE") or None)
 # Off by default: parity-green, but inside the replayed forward it does not beat implicit GEMM + GroupNorm launch yet
 # (profiles/r02_pconv_*): 3.61 ms vs 3.52 ms per forward with the "auto" rule below.
 PCONV_MODE = os.environ.get("UPGPT_PCONV", "0")
+QPROJ_FUSE = os.environ.get("UPGPT_QPROJ_FUSE", "1") == "1"
 GN_REDUCE_APPLY = os.environ.get("UPGPT_GN_REDUCE_APPLY", "1") == "1"
 PCONV_ON = PCONV_MODE != "0"
 LN_LAUNCH_US = 3.0  # what a separate LayerNorm launch costs inside the replayed forward (class ablation: 3.8)
@@ -185,6 +186,23 @@ class Packer:
 
     def vec(self, name):
         return self.get(name).float().contiguous()
+
+
+def qproj_pack(w, gamma, beta, heads, dh, dp, cq, dev):
+    """to_q weight [heads*dh, C] (+ the LayerNorm affine in front of it) -> operands of upk_attention_qproj_f16
+    (include/upk.h): fp16 [heads][dp (row-permuted)][cq] with gamma folded in, fp32 column sums of the rounded rows and
+    W beta, both [heads*dp] in natural order (head dim zero-padded dh -> dp, channels C -> cq)."""
+    C_ = w.shape[1]
+    wf = torch.zeros(heads, dp, cq, dtype=torch.float32, device=dev)
+    wf[:, :dh, :C_] = (w.float().to(dev) * gamma.float().to(dev)[None, :]).reshape(heads, dh, C_)
+    bias = torch.zeros(heads, dp, dtype=torch.float32, device=dev)
+    bias[:, :dh] = (w.float().to(dev) @ beta.float().to(dev)).reshape(heads, dh)
+    w16 = wf.half()
+    colsum = w16.float().sum(dim=2)
+    r = torch.arange(dp, device=dev)
+    kd, t, m = r // 32, (r % 32) // 16, r % 16
+    src = 32 * kd + 8 * (m // 4) + 4 * t + (m % 4)  # packed row r holds natural row src
+    return w16[:, src, :].contiguous(), colsum.reshape(-1).contiguous(), bias.reshape(-1).contiguous()
 
 
 def pad_rows_map(parts, heads, dh, dp):
@@ -652,6 +670,9 @@ class PackedUNet:
                                                       bias=False, ln=(t + ".norm2") if fold else None)
                     w[t + ".ff.geglu" + sfx] = pk.pack(t + ".ff.net.0.proj", row_map=geglu_rows_map(4 * heads * dh),
                                                        n_out=4 * heads * dh, ln=(t + ".norm3") if fold else None)
+                if dp in (32, 64) and Lr.ch % 224 == 0:  # operands of the attention that projects its own queries
+                    w[t + ".attn2.qproj"] = qproj_pack(get(t + ".attn2.to_q.weight"), get(t + ".norm2.weight"),
+                                                       get(t + ".norm2.bias"), heads, dh, dp, Lr.ch, ctx.device)
                 w[t + ".attn1.to_out"] = pk.pack(t + ".attn1.to_out.0", col_map=to_out_cols)
                 w[t + ".attn2.kv"] = pk.pack([t + ".attn2.to_k", t + ".attn2.to_v"],
                                              row_map=pad_rows_map(2, heads, dh, dp), bias=False, n_out=hd)
@@ -786,11 +807,25 @@ class UNetPlan(Emitter):
         P.attn_flops += 4 * B * heads * HW * HW * dh
         t1 = self.conv(P, a1, w[t + ".attn1.to_out"], residual=t0)
         # cross-attention over the (precomputed) context K / V
-        q2 = self.ln_linear(P, t1, t + ".attn2.q", t + ".norm2")
         kc, vtc, cld = self.kv[n]
         a2 = Act(self.alloc(M, hd), B, x.H, x.W, hd)
-        self.attention(P, q2.t, hd, HW * hd, kc.t, hd, self.n_ctx * hd, vtc, cld, a2.t, hd, HW * hd, B, heads, HW,
-                       self.n_ctx, dp, scale)
+        # (pays while there are >= 2 waves per SIMD to hide a wave's serial projection -> scores chain: 32x32 level
+        # 16 -> 12 us per block; at 16x16 (1 wave per SIMD, 4x the weight slice per wave) 16 -> 18 us)
+        if (QPROJ_FUSE and (t + ".attn2.qproj") in w and t1.C == t1.ld and dp == 32
+                and B * heads * ((HW + 31) // 32) >= 2048):
+            # norm2 -> to_q inside the attention kernel (include/upk.h upk_attention_qproj_f16): no q GEMM, no q tensor
+            wq, wu, wb = w[t + ".attn2.qproj"]
+            fn, hh, chk = self.lib.upk_attention_qproj_f16, self.hctx, self._chk
+            qa = (t1.t.data_ptr(), t1.ld, HW * t1.ld, t1.C, t1.C, 1e-5, wq.data_ptr(), wu.data_ptr(), wb.data_ptr(),
+                  kc.t.data_ptr(), hd, self.n_ctx * hd, vtc.data_ptr(), cld, a2.t.data_ptr(), hd, HW * hd, B, heads, HW,
+                  self.n_ctx, dp, float(scale))
+            P.add(lambda s: chk(fn(hh, *qa, s)), t1, wq, wu, wb, kc, vtc, a2, cls="attention",
+                  label="attn+q B%d h%d nq%d nkv%d d%d C%d" % (B, heads, HW, self.n_ctx, dp, t1.C))
+            P.igemm_flops += 2 * M * heads * dh * t1.C
+        else:
+            q2 = self.ln_linear(P, t1, t + ".attn2.q", t + ".norm2")
+            self.attention(P, q2.t, hd, HW * hd, kc.t, hd, self.n_ctx * hd, vtc, cld, a2.t, hd, HW * hd, B, heads, HW,
+                           self.n_ctx, dp, scale)
         P.attn_flops += 4 * B * heads * HW * self.n_ctx * dh
         t2 = self.conv(P, a2, w[t + ".attn2.to_out"], residual=t1)
         # GEGLU feed-forward
