@@ -193,6 +193,16 @@ typedef struct upk_conv_desc {
   void* gno_y;
   float gno_eps;
   int32_t gno_silu, gno_ld, gno_skip_y;
+  /* LayerNorm row statistics handed from the launch that PRODUCES a tensor to the folded-LayerNorm Linear that reads
+   * it (BasicTransformerBlock: attn1/attn2 to_out -> norm2/norm3 -> to_q / GEGLU proj, proj_in -> norm1 -> q|k|v;
+   * attention.py:203-215).  Producer: ln_rows_out = [8][M][2] floats; a plain-epilogue launch that does not split K
+   * writes, per output row and per column slot, the sum and the sum of squares of the fp16 values it stores
+   * (upk_conv_ln_rows reports the slot count, 0 = this launch cannot).  Consumer: ln_colsum / ln_eps / ln_dim as
+   * for the in-kernel fold, plus ln_rows_in (the producer's buffer) and ln_rows_slots: the row statistics are read
+   * instead of being taken from the operand tile, so every tile configuration can run the GEMM. */
+  float* ln_rows_out;
+  const float* ln_rows_in;
+  int32_t ln_rows_slots;
 } upk_conv_desc;
 
 /* Replaces F.conv2d (3x3 s1/s2 p1, 1x1) / F.linear call sites:
@@ -207,6 +217,9 @@ int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream)
  * {0, 1, 2, 3}, *nblk = row blocks per sample for mode 2; 3 = the reduce pass applies the GroupNorm itself (gno_*) and
  * leaves no statistics.  Nothing is enqueued. */
 int upk_conv_gn_fused(upk_ctx* ctx, const upk_conv_desc* d, int* mode, int* nblk);
+/* Number of column slots upk_conv2d_nhwc_f16(d) will fill in d->ln_rows_out (0: none — the launch splits K, has no
+ * plain epilogue, or runs a K-split tile configuration).  Nothing is enqueued. */
+int upk_conv_ln_rows(upk_ctx* ctx, const upk_conv_desc* d, int* slots);
 
 /* Tile configurations of the A-stationary patch kernel (upk_conv_desc.pc_enable / pc_cfg). */
 int upk_pconv_num_configs(void);

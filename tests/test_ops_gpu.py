@@ -1,5 +1,6 @@
 """Op-level parity of the HIP kernels (through the C ABI) against plain PyTorch fp32
 references of the same op, fed the same fp16-rounded inputs."""
+import ctypes as C
 import math
 
 import pytest
@@ -861,3 +862,100 @@ def test_attention_with_query_projection_inside(ctx, C, heads, dh, nq, nkv):
     got = out.view(B, nq, heads, dp)[..., :dh].transpose(1, 2)
     check(got, ref, tol=1e-2)
     assert not out.view(B, nq, heads, dp)[..., dh:].any()  # the padded head columns stay zero
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,C,N,flags", [(8192, 224, 768, 0), (2048, 448, 512, 0), (512, 896, 1024, 0), (512, 896, 7168, L.F_GEGLU),
+                                         (200, 224, 256, 0)])
+def test_layernorm_rows_from_producer(ctx, M, C, N, flags):
+    """include/upk.h ln_rows_*: a residual GEMM leaves the LayerNorm row sums of its output, the folded-LayerNorm
+    Linear behind it takes them from there — on every tile configuration family (wave-specialised M x N split, K-split,
+    classic) — and matches LayerNorm + Linear (+ GEGLU) in PyTorch; producers that cannot say so."""
+    import ctypes as ct
+    K0 = 256
+    a0 = rnd(M, K0).half()
+    w0 = rnd(C, K0, seed=1, scale=1 / math.sqrt(K0))
+    b0 = rnd(C, seed=2, scale=0.1)
+    res = (rnd(M, C, seed=3) * 1.5 + 0.3).half()
+    t = torch.zeros(M, C, device=DEV, dtype=torch.float16)
+    dp = make_desc(ctx, a0.view(1, M, 1, K0), w0.view(C, K0, 1, 1), b0, t.view(1, M, 1, C), residual=res.view(1, M, 1, C))
+    rows = torch.zeros(8, M, 2, device=DEV)
+    dp.ln_rows_out = rows.data_ptr()
+    gamma, beta = 1 + 0.2 * rnd(C, seed=4), 0.1 * rnd(C, seed=5)
+    w1 = rnd(N, C, seed=6, scale=1 / math.sqrt(C))
+    b1 = rnd(N, seed=7, scale=0.1)
+    t_ref = (F.linear(a0.float(), w0.half().float(), b0) + res.float()).half().float()
+    y_ref = F.linear(F.layer_norm(t_ref, (C,), gamma, beta, 1e-5), w1, b1)
+    n_cols = N
+    if flags & L.F_GEGLU:
+        v, g = y_ref.chunk(2, dim=-1)
+        y_ref, n_cols = v * F.gelu(g), N // 2
+    wf = (w1 * gamma[None, :])
+    bf = b1 + w1 @ beta
+    row_map = None
+    if flags & L.F_GEGLU:
+        from upgpt_amd.engine import geglu_rows_map
+        row_map = geglu_rows_map(N // 2).to(DEV).int()
+    names = [ctx.lib.upk_conv_config_name(i).decode() for i in range(ctx.lib.upk_conv_num_configs())]
+    fam = {"mxn": [i for i, n in enumerate(names) if "w" in n and "x1x1k" not in n],
+           "ksplit": [i for i, n in enumerate(names) if "x1x1k" in n],
+           "classic": [i for i, n in enumerate(names) if "w" not in n]}
+    try:
+        # producer on an M x N-split configuration: statistics available
+        ran_p = None
+        for cfg in fam["mxn"]:
+            ctx.conv_override(cfg, 1)
+            slots = ct.c_int()
+            try:
+                ctx._chk(ctx.lib.upk_conv_ln_rows(ctx.h, ct.byref(dp), ct.byref(slots)))
+            except L.UpkError:
+                continue
+            if slots.value > 0:
+                ctx.conv(dp)
+                ran_p = slots.value
+                break
+        assert ran_p, "no M x N-split configuration took the producer"
+        torch.cuda.synchronize()
+        check(t, t_ref)
+        tt = t.float()
+        got = rows[:ran_p].sum(0)
+        assert torch.allclose(got[:, 0], tt.sum(1), rtol=1e-3, atol=1e-2)
+        assert torch.allclose(got[:, 1], (tt * tt).sum(1), rtol=1e-3, atol=1e-2)
+        # a K-split producer cannot
+        for cfg in fam["ksplit"][:3]:
+            ctx.conv_override(cfg, 1)
+            slots = ct.c_int(5)
+            try:
+                ctx._chk(ctx.lib.upk_conv_ln_rows(ctx.h, ct.byref(dp), ct.byref(slots)))
+            except L.UpkError:
+                continue
+            assert slots.value == 0
+        # consumer on every family
+        for name, cfgs in fam.items():
+            ran = 0
+            for cfg in cfgs:
+                y = torch.zeros(M, n_cols, device=DEV, dtype=torch.float16)
+                dc = make_desc(ctx, t.view(1, M, 1, C), wf.view(N, C, 1, 1), bf, y.view(1, M, 1, n_cols), flags=flags,
+                               n_out=n_cols if flags & L.F_GEGLU else None, row_map=row_map)
+                colsum = torch.zeros(dc.n_pad, device=DEV)
+                wq = wf.half().float().sum(1)
+                if row_map is not None:
+                    m = row_map.long()
+                    colsum[: m.numel()] = torch.where(m >= 0, wq[m.clamp(min=0)], torch.zeros_like(wq[m.clamp(min=0)]))
+                else:
+                    colsum[:N] = wq
+                dc.ln_colsum, dc.ln_eps, dc.ln_dim = colsum.data_ptr(), 1e-5, C
+                dc.ln_rows_in, dc.ln_rows_slots = rows.data_ptr(), ran_p
+                ctx.conv_override(cfg, 1)
+                try:
+                    ctx.conv(dc)
+                except L.UpkError:
+                    continue
+                torch.cuda.synchronize()
+                check(y, y_ref, tol=3e-2)
+                ran += 1
+                if ran >= 3:
+                    break
+            assert ran >= 1 or name != "mxn", "no %s configuration ran the consumer" % name
+    finally:
+        ctx.conv_override(-1, 0)

@@ -18,7 +18,7 @@ SYMBOLS = [
     "upk_version", "upk_create", "upk_destroy", "upk_last_error", "upk_set_workspace", "upk_num_cus",
     "upk_pack_weight_f16", "upk_packed_weight_bytes", "upk_conv2d_nhwc_f16", "upk_gemm_f16",
     "upk_conv_autotune", "upk_conv_override", "upk_conv_num_configs", "upk_conv_config_name", "upk_conv_gn_fused",
-    "upk_pconv_num_configs", "upk_pconv_config_name", "upk_pconv_supported",
+    "upk_pconv_num_configs", "upk_pconv_config_name", "upk_pconv_supported", "upk_conv_ln_rows",
     "upk_attention_f16", "upk_groupnorm_nhwc_f16", "upk_groupnorm_stats_nhwc_f16", "upk_groupnorm_chunks", "upk_groupnorm_apply_nhwc_f16", "upk_groupnorm_ws_bytes",
     "upk_layernorm_f16", "upk_timestep_embed_f16",
     "upk_nchw_f32_to_nhwc_f16", "upk_nhwc_f16_to_nchw_f32", "upk_f32_to_f16", "upk_ddim_step_f32",
@@ -66,6 +66,7 @@ class ConvDesc(C.Structure):
         ("gni_nblk1", C.c_int32), ("gni_ld1", C.c_int32), ("gni_nblk2", C.c_int32), ("gni_ld2", C.c_int32),
         ("gno_gamma", C.c_void_p), ("gno_beta", C.c_void_p), ("gno_y", C.c_void_p), ("gno_eps", C.c_float),
         ("gno_silu", C.c_int32), ("gno_ld", C.c_int32), ("gno_skip_y", C.c_int32),
+        ("ln_rows_out", C.c_void_p), ("ln_rows_in", C.c_void_p), ("ln_rows_slots", C.c_int32),
     ]
 
 
@@ -105,6 +106,7 @@ def load_library(path=None):
             "upk_pconv_num_configs": (C.c_int, []),
             "upk_pconv_config_name": (C.c_char_p, [i32]),
             "upk_pconv_supported": (C.c_int, [vp, C.POINTER(ConvDesc)]),
+            "upk_conv_ln_rows": (C.c_int, [vp, C.POINTER(ConvDesc), C.POINTER(C.c_int)]),
             "upk_attention_f16": (C.c_int, [vp, vp, i32, i64, vp, i32, i64, vp, i32, vp, i32, i64,
                                             i32, i32, i32, i32, i32, f32, vp]),
             "upk_attention_causal_f16": (C.c_int, [vp, vp, i32, i64, vp, i32, i64, vp, i32, vp, i32, i64,

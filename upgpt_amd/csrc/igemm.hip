@@ -249,6 +249,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
     }
     return;
   }
+  if (a.lnr_in) Epi::lnr_fix<MI, NI>(a, mw, nw, lc, lg, acc);  // folded LayerNorm, row sums from the producer
   Epi::tile<MI, NI, WM, WN>(a, m0, mw, nw, lc, lg, acc, wm, wn, (float*)smem, a.M);
 }
 
@@ -600,7 +601,9 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
         const int f = wave + 4 * q;
         if (f >= NF) continue;
         const int j = f - (f / NI) * NI;
-        const f16x4 o = Epi::Plain::put(a, rows[q], n0 + j * 16 + lg * 4, frag_sum(f) + bvs[q] + rvs[q], rrs[q]);
+        f32x4 fs = frag_sum(f);
+        if (a.lnr_in) fs = Epi::lnr_fix1(a, m0 + (f / NI) * 16 + lc, n0 + j * 16 + lg * 4, fs);
+        const f16x4 o = Epi::Plain::put(a, rows[q], n0 + j * 16 + lg * 4, fs + bvs[q] + rvs[q], rrs[q]);
         if (a.gn_cp) {
           f32x4 su, sq;
 #pragma unroll
@@ -656,9 +659,17 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
       const int n = n0 + j * 16 + lg * 4;
       if (n >= a.npad) continue;
       if (geglu) {
-        if ((j & 2) == 0 && j + 2 < NI) Epi::store(a, rcs[q], n, frag_sum(f), frag_sum(f + 2), bvs[q], bgs[q], ins[q]);
+        if ((j & 2) == 0 && j + 2 < NI) {
+          f32x4 v = frag_sum(f), gte = frag_sum(f + 2);
+          if (a.lnr_in) {
+            v = Epi::lnr_fix1(a, m0 + i * 16 + lc, n, v);
+            gte = Epi::lnr_fix1(a, m0 + i * 16 + lc, n + 32, gte);
+          }
+          Epi::store(a, rcs[q], n, v, gte, bvs[q], bgs[q], ins[q]);
+        }
       } else {
-        const f32x4 v = frag_sum(f);
+        f32x4 v = frag_sum(f);
+        if (a.lnr_in) v = Epi::lnr_fix1(a, m0 + i * 16 + lc, n, v);
         Epi::store(a, rcs[q], n, v, v, bvs[q], bvs[q], ins[q]);
       }
     }
@@ -686,6 +697,8 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
 #pragma unroll
       for (int j = 0; j < NI; ++j) acc[i][j] = (acc[i][j] - mean * u[j]) * rstd;
     }
+  } else if (a.lnr_in) {
+    Epi::lnr_fix<MI, NI>(a, mw, nw, lc, lg, acc);
   }
   if ABL_ON(ABL_NOEPI) {
     float t = 0.f;
@@ -1088,7 +1101,8 @@ extern "C" int upk_conv_override(upk_ctx* ctx, int cfg, int splitk) {
 // launch == false: stops after the (config, split-K) decision and reports whether the reduce pass will
 // produce GroupNorm partials (upk_conv_gn_fused)
 static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, bool launch, int* gn_fused,
-                     int* gn_nblk = nullptr, bool* on_patch = nullptr) {
+                     int* gn_nblk = nullptr, bool* on_patch = nullptr, int* lnr_slots = nullptr) {
+  if (lnr_slots) *lnr_slots = 0;
   if (!ctx || !d) return UPK_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   if (!d->x1 || !d->w_packed || !d->y) return upk_fail(ctx, UPK_EINVAL, "conv: null x1/w/y");
@@ -1159,6 +1173,11 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   a.ln_u = d->ln_colsum;
   a.ln_eps = d->ln_eps;
   a.ln_inv_dim = d->ln_dim > 0 ? 1.0f / (float)d->ln_dim : 0.f;
+  a.lnr_out = nullptr;
+  a.lnr_in = a.ln_u ? d->ln_rows_in : nullptr;
+  a.lnr_slots = d->ln_rows_slots;
+  if (a.lnr_in && (a.lnr_slots < 1 || a.lnr_slots > 8))
+    return upk_fail(ctx, UPK_EINVAL, "conv: ln_rows_slots must be 1..8");
   if (a.ln_u && (!a.linear || d->c2 != 0 || d->ln_dim <= 0 || d->ln_dim > d->c1))
     return upk_fail(ctx, UPK_EINVAL, "conv: folded LayerNorm needs a 1x1 stride-1 single-source launch, 0 < ln_dim <= c1");
   a.cpt = (a.c1 + a.c2) / 32;
@@ -1202,7 +1221,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   for (int c = 0; c < kNumCfgs; ++c) {
     if (want_cfg >= 0 && c != want_cfg) continue;
     // folded LayerNorm: row statistics come from the M x N-split wave-specialised kernels, whole K in one block
-    if (a.ln_u && !kCfgs[c].fn_ln) continue;
+    if (a.ln_u && !a.lnr_in && !kCfgs[c].fn_ln) continue;
     if (a.x3 && !kCfgs[c].fn_app) continue;  // the appended K segment lives in the wave-specialised loader
     for (int sk : sk_cands) {
       if (want_sk > 0 && sk != want_sk) continue;
@@ -1259,6 +1278,14 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     a.gn_nblk = hw_out / BM;
     a.gn_hw = hw_out;
   }
+  // LayerNorm row sums of the output for the consumer GEMM (Epi::tile_plain_lnr): M x N-split epilogue only
+  if (d->ln_rows_out && zdim == 1 && Epi::plain(a) && !gn_cp && c.wm * c.wn > 1) {
+    const int slots = a.tiles_n * c.wn;
+    if (slots <= 8) {
+      a.lnr_out = d->ln_rows_out;
+      if (lnr_slots) *lnr_slots = slots;
+    }
+  }
   if (gn_fused) *gn_fused = gn_apply ? 3 : (gn_fuse ? 1 : (gn_cp ? 2 : 0));
   if (gn_nblk) *gn_nblk = gn_cp ? a.gn_nblk : 0;
   if (!launch) return UPK_OK;
@@ -1280,7 +1307,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
 #endif
   upk_prof_scope prof(ctx, UPK_CLS_IGEMM, stream);
   dim3 grid(a.tiles_m * a.tiles_n, 1, zdim);
-  hipLaunchKernelGGL(a.ln_u ? c.fn_ln : (a.x3 ? c.fn_app : c.fn), grid, dim3(c.nbuf ? 512 : c.wm * c.wn * 64), 0, stream, a);
+  hipLaunchKernelGGL((a.ln_u && !a.lnr_in) ? c.fn_ln : (a.x3 ? c.fn_app : c.fn), grid, dim3(c.nbuf ? 512 : c.wm * c.wn * 64), 0, stream, a);
   int rc = upk_check_launch(ctx, "igemm");
   if (rc) return rc;
   if (zdim > 1 && gn_apply) {
@@ -1341,6 +1368,11 @@ extern "C" int upk_pconv_supported(upk_ctx* ctx, const upk_conv_desc* d) {
   const int rc = conv_impl(ctx, &dd, nullptr, false, nullptr, nullptr, &on_patch);
   ctx->err[0] = 0;
   return rc == UPK_OK && on_patch ? 1 : 0;
+}
+
+extern "C" int upk_conv_ln_rows(upk_ctx* ctx, const upk_conv_desc* d, int* slots) {
+  if (!slots) return UPK_EINVAL;
+  return conv_impl(ctx, d, nullptr, false, nullptr, nullptr, nullptr, slots);
 }
 
 extern "C" int upk_conv_gn_fused(upk_ctx* ctx, const upk_conv_desc* d, int* mode, int* nblk) {

@@ -82,6 +82,11 @@ struct IgemmArgs {
   const float* gni_s1;  // mode 1: [B][nblk1][groups][2]; mode 2: [B][nblk1][2][ld1] of source 1
   const float* gni_s2;  // mode 2: partials of the second (concat) source
   int gni_nblk1, gni_ld1, gni_nblk2, gni_ld2;
+  // ---- LayerNorm row statistics handed from the producer of a tensor to the folded-LayerNorm GEMM that reads it
+  float* lnr_out;        // plain epilogue also writes per-(column slot, row) {sum, sum of squares} of what it stores:
+                         // [slots][M][2], slot = (output column) / (columns per wave); nullptr: no
+  const float* lnr_in;   // folded LayerNorm (ln_u) takes the row statistics from here ([lnr_slots][M][2]) instead of
+  int lnr_slots;         // from the A fragments: any kernel family can run the GEMM
 };
 
 // 16-byte chunk swizzle for a [rows][4 chunks] fp16 tile (64 B rows).
@@ -100,7 +105,57 @@ struct RowCtx {
   unsigned y_off, res_off, rv_off, vt_off, nchw_off;
 };
 
+// sum over the four lanes (c, c+16, c+32, c+48) that hold the columns of one row of a fragment (gfx950 permlane swaps:
+// VALU, no LDS round trip); every lane ends with the total
+__device__ __forceinline__ float sum_lane_groups(float x) {
+  unsigned u = __builtin_bit_cast(unsigned, x);
+  const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  u = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]));
+  const auto b = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+}
+
 struct Epi {
+  // folded LayerNorm with the row statistics from memory (IgemmArgs::lnr_in): {mean, rstd} of row m
+  static __device__ __forceinline__ void lnr_row(const IgemmArgs& a, int m, float& mean, float& rstd) {
+    const float* p = a.lnr_in + (long)(m < a.M ? m : 0) * 2;
+    const long sstride = (long)a.M * 2;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {  // (all loads issued before the first use)
+      const f32x2 v = s < a.lnr_slots ? *(const f32x2*)(p + s * sstride) : (f32x2){0.f, 0.f};
+      s1 += v[0];
+      s2 += v[1];
+    }
+    mean = s1 * a.ln_inv_dim;
+    rstd = rsqrtf(fmaxf(s2 * a.ln_inv_dim - mean * mean, 0.f) + a.ln_eps);
+  }
+  // y = rstd * (acc - mean * colsum) on a wave's accumulator tile (lane (lc, lg): row mw + 16 i + lc).  The loads sit
+  // in the epilogue: holding {mean, rstd} of the MI row groups across the K loop instead (requested at kernel start)
+  // costs every launch of the kernel 2*MI registers — measured: the 3x3 224->224 conv with residual 22 -> 31 us
+  template <int MI, int NI>
+  static __device__ __forceinline__ void lnr_fix(const IgemmArgs& a, int mw, int nw, int lc, int lg, f32x4 (&acc)[MI][NI]) {
+    f32x4 u[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = nw + j * 16 + lg * 4;
+      u[j] = n < a.npad ? *(const f32x4*)(a.ln_u + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    float mean[MI], rstd[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) lnr_row(a, mw + i * 16 + lc, mean[i], rstd[i]);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = (acc[i][j] - mean[i] * u[j]) * rstd[i];
+  }
+  static __device__ __forceinline__ f32x4 lnr_fix1(const IgemmArgs& a, int m, int n, f32x4 v) {
+    float mean, rstd;
+    lnr_row(a, m, mean, rstd);
+    const f32x4 u = n < a.npad ? *(const f32x4*)(a.ln_u + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    return (v - mean * u) * rstd;
+  }
+
   static __device__ __forceinline__ RowCtx row(const IgemmArgs& a, int m, int mlim) {
     RowCtx r;
     r.ok = m < mlim;
@@ -320,6 +375,47 @@ struct Epi {
     }
   }
 
+  // tile_plain that also leaves the LayerNorm row sums of what it stores (IgemmArgs::lnr_out): per row the sum / sum
+  // of squares of the fp16-rounded outputs over this wave's NI*16 columns — in-lane over the fragments, permlane swaps
+  // over the four lane groups — one partial slot per wave column; the consumer adds the slots of a row
+  template <int MI, int NI>
+  static __device__ __forceinline__ void tile_plain_lnr(const IgemmArgs& a, int mw, int nw, int lc, int lg,
+                                                        const f32x4 (&acc)[MI][NI], int mlim) {
+    const Plain P(a);
+    f32x4 bv[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) bv[j] = P.bias4(a, nw + j * 16 + lg * 4);
+    float* dst = a.lnr_out + (long)(nw / (NI * 16)) * a.M * 2;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const Plain::Row r = P.row(a, mw + i * 16 + lc, mlim);
+      f32x4 rv[NI];
+      f16x4 rr[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        rv[j] = P.rv4(a, r, nw + j * 16 + lg * 4);
+        rr[j] = P.res4(a, r, nw + j * 16 + lg * 4);
+      }
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = nw + j * 16 + lg * 4;
+        const f16x4 o = Plain::put(a, r, n, acc[i][j] + bv[j] + rv[j], rr[j]);
+        if (n < a.n_out) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float f = (float)o[k];
+            s1 += f;
+            s2 += f * f;
+          }
+        }
+      }
+      s1 = sum_lane_groups(s1);
+      s2 = sum_lane_groups(s2);
+      if (lg == 0 && r.ok) *(f32x2*)(dst + (long)(mw + i * 16 + lc) * 2) = (f32x2){s1, s2};
+    }
+  }
+
   // (separate from tile_plain: the extra accumulators and the workgroup barrier must not weigh on every launch)
   template <int MI, int NI, int WM, int WN>
   static __device__ __forceinline__ void tile_plain_cp(const IgemmArgs& a, int m0, int mw, int nw, int lc, int lg,
@@ -432,6 +528,7 @@ struct Epi {
                                               const f32x4 (&acc)[MI][NI], int wm, int wn, float* red, int mlim) {
     if (plain(a)) {
       if (a.gn_cp) tile_plain_cp<MI, NI, WM, WN>(a, m0, mw, nw, lc, lg, acc, wm, wn, red, mlim);
+      else if (a.lnr_out) tile_plain_lnr<MI, NI>(a, mw, nw, lc, lg, acc, mlim);
       else tile_plain<MI, NI>(a, mw, nw, lc, lg, acc, mlim);
       return;
     }

@@ -67,6 +67,7 @@ TUNE_CACHE = TuneCache(os.environ.get("UPGPT_TUNE_FILE") or None)
 # Off by default: parity-green, but inside the replayed forward it does not beat implicit GEMM + GroupNorm launch yet
 # (profiles/r02_pconv_*): 3.61 ms vs 3.52 ms per forward with the "auto" rule below.
 PCONV_MODE = os.environ.get("UPGPT_PCONV", "0")
+LN_ROWS = os.environ.get("UPGPT_LN_ROWS", "1") == "1"
 QPROJ_FUSE = os.environ.get("UPGPT_QPROJ_FUSE", "1") == "1"
 GN_REDUCE_APPLY = os.environ.get("UPGPT_GN_REDUCE_APPLY", "1") == "1"
 PCONV_ON = PCONV_MODE != "0"
@@ -82,10 +83,11 @@ def head_pad(d):
 
 class Act:
     """[B*H*W, ld] fp16 activation (C valid channels)."""
-    __slots__ = ("t", "B", "H", "W", "C", "gn_src")
+    __slots__ = ("t", "B", "H", "W", "C", "gn_src", "ln_src")
 
     def __init__(self, t, B, H, W, C):
         self.t, self.B, self.H, self.W, self.C = t, B, H, W, C
+        self.ln_src = None  # ConvDesc of the launch that wrote this tensor (it may leave LayerNorm row sums)
         self.gn_src = None  # (producer ConvDesc, stats buffer) when the producer may have left GroupNorm partials
 
     @property
@@ -365,7 +367,26 @@ class Emitter:
         GEMM (weights packed as name + "_ln") or LayerNorm launch + plain GEMM, whichever the tuning
         cache says is faster for this shape (the fold costs VALU work in the GEMM's MFMA waves and rules
         out the classic / K-split tile configurations; a LayerNorm launch costs ~3.8 us under replay).
-        UPGPT_LN_FOLD=0/1 forces the choice (scripts/tune.py measures both)."""
+        UPGPT_LN_FOLD=0/1 forces the choice (scripts/tune.py measures both).
+
+        When the launch that produced `x` can leave the row sums (include/upk.h ln_rows_out: plain epilogue, no
+        split-K), the fold takes them from there instead: no LayerNorm launch, no statistics work in the GEMM, any
+        tile configuration (UPGPT_LN_ROWS=0 switches this off)."""
+        prod = getattr(x, "ln_src", None)
+        if LN_ROWS and prod is not None and not prod.ln_rows_out and not prod.pc_enable and x.C == x.ld:
+            rows = self.alloc(8, x.M, 2, dtype=torch.float32)
+            prod.ln_rows_out = rows.data_ptr()
+            out = kw.pop("out", None)
+            pw = self.pk.w[name + "_ln"]
+            if out is None:  # (both programs write the same buffer)
+                assert pw.n_out % 32 == 0
+                out = Act(self.alloc(x.M, pw.n_out), x.B, x.H, x.W, pw.n_out)
+            alt = Program(self.ctx)
+            self._ln_linear_plain(alt, x, name, norm, flags, out=out, **kw)
+            return self.conv(P, x, pw, flags=flags, ln_eps=1e-5, lnr=rows, lnr_alt=alt, out=out, **kw)
+        return self._ln_linear_plain(P, x, name, norm, flags, **kw)
+
+    def _ln_linear_plain(self, P, x, name, norm, flags=0, **kw):
         w, v = self.pk.w, self.pk.v
         mode = os.environ.get("UPGPT_LN_FOLD", "auto")
         fold = mode != "0"
@@ -382,7 +403,7 @@ class Emitter:
 
     def conv(self, P, x1, pw, *, x2=None, stride=1, flags=0, residual=None, rowvec=None, rv_bs=0, rv_ss=0,
              step=None, out=None, vt=None, nchw_out=None, out_f32=None, spatial=None, ln_eps=None,
-             gn_stats=False, append=None, gn=None):
+             gn_stats=False, append=None, gn=None, lnr=None, lnr_alt=None):
         """Emits one upk_conv2d_nhwc_f16. Returns the output Act (fp16) unless nchw_out /
         out_f32 is given.
 
@@ -393,7 +414,7 @@ class Emitter:
         ks = pw.ksize
         kw_all = dict(stride=stride, flags=flags, residual=residual, rowvec=rowvec, rv_bs=rv_bs, rv_ss=rv_ss, step=step,
                       out=out, vt=vt, nchw_out=nchw_out, out_f32=out_f32, spatial=spatial, ln_eps=ln_eps,
-                      gn_stats=gn_stats, append=append)
+                      gn_stats=gn_stats, append=append, lnr=lnr, lnr_alt=lnr_alt)
         if gn is not None and not PCONV_ON:
             return self.conv(P, self.groupnorm(P, x1, *gn[:5], x2=x2, sole=len(gn) > 5 and gn[5]), pw, **kw_all)
         ups = bool(flags & L.F_UPSAMPLE2X)
@@ -457,6 +478,11 @@ class Emitter:
             # (armed by the consuming groupnorm(): a by-product nobody reads costs epilogue time and would mislead
             # the tuner's credit for the saved gn_stats launch)
             ret.gn_src = (d, len(self.convs))
+        if ret is not None and vt is None and not (flags & (L.F_GEGLU | L.F_SILU)):
+            ret.ln_src = d  # (a LayerNorm-folded consumer may ask this launch for the row statistics, see ln_linear)
+        if lnr is not None:  # folded LayerNorm with the row statistics from x1's producer (include/upk.h ln_rows_*)
+            d.ln_rows_in = lnr.data_ptr()
+            d.ln_rows_slots = 1  # (set from the producer's answer when the program runs)
         if ln_eps is not None:  # x1 is the un-normalised residual stream; pw was packed with ln=...
             assert pw.ln_colsum is not None and x2 is None and ks == 1
             d.ln_colsum = pw.ln_colsum.data_ptr()
@@ -484,14 +510,30 @@ class Emitter:
                 self.bufs.pop()  # (the output buffer allocated above is re-made by the plain call)
             return self.conv(P, self.groupnorm(P, x1, *gn[:5], x2=x2, sole=len(gn) > 5 and gn[5]), pw, **kw_all)
         key = self.conv_key(M, pw.n_pad, d.c1, d.c2, ks, stride, flags, residual is not None, rowvec is not None,
-                            vt is not None, ln_eps is not None, ka=d.c3 + d.c4)
+                            vt is not None, ln_eps is not None and lnr is None, ka=d.c3 + d.c4)
         if use_pc:
             key += "_pc" + ("" if gn is None else "_gn%d" % int(bool(gn[3])))
         self.convs.append((d, key))
         fn, h, ref = self.lib.upk_conv2d_nhwc_f16, self.hctx, C.byref(d)
         chk = self._chk
         keep = (d, pw, x1, x2, x3, x4, residual, rowvec, out, nchw_out, out_f32, vt)
-        if gn is None:
+        if lnr is not None:
+            # the producer of x1 leaves the LayerNorm row sums when its (tuned) launch can (plain epilogue, no split-K,
+            # M x N-split tile); otherwise the alternative program runs: LayerNorm launch / in-kernel fold
+            prod, alt = x1.ln_src, lnr_alt
+            ask = self.lib.upk_conv_ln_rows
+
+            def run_lnr(s):
+                slots = C.c_int(0)
+                chk(ask(h, C.byref(prod), C.byref(slots)))
+                if slots.value > 0:
+                    d.ln_rows_slots = slots.value
+                    chk(fn(h, ref, s))
+                else:
+                    alt.run(s)
+
+            P.add(run_lnr, *keep, lnr, prod, alt, cls="igemm_k%d" % ks, label=key + "_lnr")
+        elif gn is None:
             P.add(lambda s: chk(fn(h, ref, s)), *keep, cls="igemm_k%d" % ks, label=key)
         else:
             gamma, beta, eps, silu, ws = gn[:5]
