@@ -217,8 +217,8 @@ int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream)
  * {0, 1, 2, 3}, *nblk = row blocks per sample for mode 2; 3 = the reduce pass applies the GroupNorm itself (gno_*) and
  * leaves no statistics.  Nothing is enqueued. */
 int upk_conv_gn_fused(upk_ctx* ctx, const upk_conv_desc* d, int* mode, int* nblk);
-/* Number of column slots upk_conv2d_nhwc_f16(d) will fill in d->ln_rows_out (0: none — the launch splits K, has no
- * plain epilogue, or runs a K-split tile configuration).  Nothing is enqueued. */
+/* Number of column slots upk_conv2d_nhwc_f16(d) will fill in d->ln_rows_out (0: none — the launch splits K across workgroups or has no
+ * plain epilogue).  Nothing is enqueued. */
 int upk_conv_ln_rows(upk_ctx* ctx, const upk_conv_desc* d, int* slots);
 
 /* Tile configurations of the A-stationary patch kernel (upk_conv_desc.pc_enable / pc_cfg). */

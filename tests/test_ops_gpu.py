@@ -921,15 +921,30 @@ def test_layernorm_rows_from_producer(ctx, M, C, N, flags):
         got = rows[:ran_p].sum(0)
         assert torch.allclose(got[:, 0], tt.sum(1), rtol=1e-3, atol=1e-2)
         assert torch.allclose(got[:, 1], (tt * tt).sum(1), rtol=1e-3, atol=1e-2)
-        # a K-split producer cannot
-        for cfg in fam["ksplit"][:3]:
+        # a K-split producer leaves them too (one slot per N tile)
+        for cfg in fam["ksplit"]:
             ctx.conv_override(cfg, 1)
-            slots = ct.c_int(5)
+            slots = ct.c_int(0)
             try:
                 ctx._chk(ctx.lib.upk_conv_ln_rows(ctx.h, ct.byref(dp), ct.byref(slots)))
             except L.UpkError:
                 continue
-            assert slots.value == 0
+            if slots.value > 0:
+                rows.zero_()
+                t.zero_()
+                ctx.conv(dp)
+                torch.cuda.synchronize()
+                check(t, t_ref)
+                got = rows[:slots.value].sum(0)
+                assert torch.allclose(got[:, 0], tt.sum(1), rtol=1e-3, atol=1e-2)
+                assert torch.allclose(got[:, 1], (tt * tt).sum(1), rtol=1e-3, atol=1e-2)
+                ran_p = slots.value
+                break
+        # a launch that splits K across workgroups cannot
+        ctx.conv_override(-1, 2)
+        slots = ct.c_int(5)
+        ctx._chk(ctx.lib.upk_conv_ln_rows(ctx.h, ct.byref(dp), ct.byref(slots)))
+        assert slots.value == 0
         # consumer on every family
         for name, cfgs in fam.items():
             ran = 0

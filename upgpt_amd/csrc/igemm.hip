@@ -616,6 +616,37 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
             *(f32x4*)(cpred + f * 32 + lg * 4) = su;
             *(f32x4*)(cpred + f * 32 + 16 + lg * 4) = sq;
           }
+        } else if (a.lnr_out) {  // LayerNorm row sums of the output (IgemmArgs::lnr_out): this fragment's 16 columns
+          float s1 = 0.f, s2 = 0.f;
+          if (n0 + j * 16 + lg * 4 < a.n_out) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float v = (float)o[k];
+              s1 += v;
+              s2 += v * v;
+            }
+          }
+          s1 = sum_lane_groups(s1);
+          s2 = sum_lane_groups(s2);
+          if (lg == 0) {
+            cpred[f * 32 + lc] = s1;
+            cpred[f * 32 + 16 + lc] = s2;
+          }
+        }
+      }
+      if (a.lnr_out) {  // (workgroup-uniform) one slot per N tile: the NI column fragments of each row combined
+        __syncthreads();
+        const int t = wave * 64 + lane;
+        if (t < MI * 16) {
+          const int i = t >> 4, r = t & 15;
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            s1 += cpred[(i * NI + j) * 32 + r];
+            s2 += cpred[(i * NI + j) * 32 + 16 + r];
+          }
+          const int m = m0 + i * 16 + r;
+          if (m < a.M) *(f32x2*)(a.lnr_out + ((long)(n0 / (NI * 16)) * a.M + m) * 2) = (f32x2){s1, s2};
         }
       }
       if (a.gn_cp) {  // (workgroup-uniform)
@@ -1278,9 +1309,9 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     a.gn_nblk = hw_out / BM;
     a.gn_hw = hw_out;
   }
-  // LayerNorm row sums of the output for the consumer GEMM (Epi::tile_plain_lnr): M x N-split epilogue only
-  if (d->ln_rows_out && zdim == 1 && Epi::plain(a) && !gn_cp && c.wm * c.wn > 1) {
-    const int slots = a.tiles_n * c.wn;
+  // LayerNorm row sums of the output for the consumer GEMM (Epi::tile_plain_lnr / the K-split kernels' epilogue)
+  if (d->ln_rows_out && zdim == 1 && Epi::plain(a) && !gn_cp && (c.wm * c.wn > 1 || c.nbuf > 0)) {
+    const int slots = a.tiles_n * c.wn;  // (K-split kernels: one slot per N tile)
     if (slots <= 8) {
       a.lnr_out = d->ln_rows_out;
       if (lnr_slots) *lnr_slots = slots;
