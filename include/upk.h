@@ -203,6 +203,15 @@ typedef struct upk_conv_desc {
   float* ln_rows_out;
   const float* ln_rows_in;
   int32_t ln_rows_slots;
+  /* Upsample (openaimodel.py:109-119, model.py:41-56: F.interpolate(scale_factor=2, mode="nearest") -> conv3x3 p1) as
+   * four 2x2 convolutions on the LOW-resolution grid, 4/9 of the multiply-adds: with UPK_F_UPSAMPLE2X, ksize 3,
+   * stride 1 and w_phase != NULL the launch computes, for phase (py, px) in {0,1}^2, output pixel (2y + py, 2x + px)
+   * from low-resolution rows {y + py - 1, y + py} x columns {x + px - 1, x + px}.  w_phase = the four phase
+   * weights, each packed like a 2x2 conv weight [n_pad][2][2][c1 + c2] (upk_pack_weight_f16 with kh = kw = 2), phase
+   * p = 2 py + px at w_phase + p * n_pad * 4 * (c1 + c2) halfs, where tap (ty, tx) of phase (py, px) is the sum of
+   * the 3x3 taps (ky, kx) with (py + ky - 1) >> 1 == py + ty - 1 and likewise for x.  Plain epilogue only (bias ->
+   * fp16 NHWC / fp32); w_packed stays the 3x3 weight (used when the launch cannot take the phase form). */
+  const void* w_phase;
 } upk_conv_desc;
 
 /* Replaces F.conv2d (3x3 s1/s2 p1, 1x1) / F.linear call sites:

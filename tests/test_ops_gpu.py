@@ -974,3 +974,53 @@ def test_layernorm_rows_from_producer(ctx, M, C, N, flags):
             assert ran >= 1 or name != "mxn", "no %s configuration ran the consumer" % name
     finally:
         ctx.conv_override(-1, 0)
+
+
+def _phase_weights(ctx, w):
+    """The four 2x2 phase weights of nearest-2x -> conv3x3 (include/upk.h w_phase), from the definition: 3x3 tap k of
+    output parity p reads low-resolution offset (p + k - 1) >> 1, phase tap t reads offset p + t - 1."""
+    parts = []
+    n_pad = None
+    for py in (0, 1):
+        for px in (0, 1):
+            wp = torch.zeros(w.shape[0], w.shape[1], 2, 2, device=DEV)
+            for ky in range(3):
+                for kx in range(3):
+                    ty, tx = ((py + ky - 1) >> 1) - (py - 1), ((px + kx - 1) >> 1) - (px - 1)
+                    wp[:, :, ty, tx] += w[:, :, ky, kx]
+            packed, n_pad = ctx.pack_weight(wp.contiguous())
+            parts.append(packed.reshape(-1))
+    return torch.cat(parts).contiguous(), n_pad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,N,H,W,sk,f32", [(2, 64, 96, 8, 8, 1, False), (2, 224, 224, 16, 12, 1, False),
+                                              (8, 896, 896, 4, 4, 4, False), (1, 128, 64, 33, 17, 1, False),
+                                              (2, 96, 32, 8, 8, 2, True)])
+def test_upsample_conv_as_four_phase_convs(ctx, B, C, N, H, W, sk, f32):
+    """Upsample (openaimodel.py:109-119): F.interpolate(2x nearest) -> conv3x3, computed as four 2x2 convs on the
+    low-resolution grid (upk_conv_desc.w_phase) — against the direct form in PyTorch and against the library's own
+    full-resolution launch."""
+    x = rnd(B, C, H, W)
+    w = rnd(N, C, 3, 3, scale=1 / math.sqrt(9 * C))
+    b = rnd(N, scale=0.1)
+    ref = F.conv2d(F.interpolate(x.half().float(), scale_factor=2, mode="nearest"), w.half().float(), b, padding=1)
+    xn = nhwc16(x)
+    wph, n_pad = _phase_weights(ctx, w)
+    outs = []
+    for phased in (True, False):
+        y = torch.zeros(B, 2 * H, 2 * W, N, device=DEV, dtype=torch.float32 if f32 else torch.float16)
+        d = make_desc(ctx, xn, w, b, y, flags=L.F_UPSAMPLE2X | (L.F_OUT_F32 if f32 else 0))
+        assert d.n_pad == n_pad
+        if phased:
+            d.w_phase = wph.data_ptr()
+        try:
+            ctx.conv_override(-1, sk)
+            ctx.conv(d)
+        finally:
+            ctx.conv_override(-1, 0)
+        torch.cuda.synchronize()
+        check(y.permute(0, 3, 1, 2), ref)
+        outs.append(y)
+    # the two forms differ only by the fp16 rounding of the summed taps
+    check(outs[0], outs[1], tol=1e-2)

@@ -67,6 +67,7 @@ class ConvDesc(C.Structure):
         ("gno_gamma", C.c_void_p), ("gno_beta", C.c_void_p), ("gno_y", C.c_void_p), ("gno_eps", C.c_float),
         ("gno_silu", C.c_int32), ("gno_ld", C.c_int32), ("gno_skip_y", C.c_int32),
         ("ln_rows_out", C.c_void_p), ("ln_rows_in", C.c_void_p), ("ln_rows_slots", C.c_int32),
+        ("w_phase", C.c_void_p),
     ]
 
 

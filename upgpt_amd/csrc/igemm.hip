@@ -60,6 +60,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
   const int kc0 = blockIdx.z * a.chunks_per_split;
   const int kc1 = min(a.nchunks, kc0 + a.chunks_per_split);
 
+  const int ph = ph_id(a);  // (upsample phase launches: grid.y)
   // ---- per-thread A rows (im2col pixel decode, done once) ----
   int a_oy[A_IT], a_ox[A_IT], a_b[A_IT];
   bool a_ok[A_IT];
@@ -80,8 +81,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
       const int p = mm - b * HoWo;
       const int oy = p / a.Wo;
       a_b[i] = b;
-      a_oy[i] = oy * a.stride - a.pad_lo;
-      a_ox[i] = (p - oy * a.Wo) * a.stride - a.pad_lo;
+      a_oy[i] = oy * a.stride - (a.ph_on ? 1 - (ph >> 1) : a.pad_lo);
+      a_ox[i] = (p - oy * a.Wo) * a.stride - (a.ph_on ? 1 - (ph & 1) : a.pad_lo);
     }
   }
 
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
     const int row = (tid + i * NT) >> 2;
     b_ok[i] = (row < BN) && (n0 + row < a.npad);
   }
-  const f16* wcur = a.w + ((long)kc0 * a.npad + n0) * 32 + tid * 8;  // + i*NT*8 per B_IT
+  const f16* wcur = a.w + (long)ph * a.ph_wstride + ((long)kc0 * a.npad + n0) * 32 + tid * 8;  // + i*NT*8 per B_IT
   const long wstep = (long)a.npad * 32;
 
   // issues the global loads of the next KS K-chunks (chunks >= kc1 read as zero)
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
     return;
   }
   if (a.partial) {
-    float* slab = a.partial + (long)blockIdx.z * a.M * a.npad;  // uniform base
+    float* slab = a.partial + ((long)blockIdx.z * (a.ph_on ? 4 : 1) + ph) * a.M * a.npad;  // uniform base
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = mw + i * 16 + lc;
@@ -319,6 +320,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
   const int kc0 = blockIdx.z * a.chunks_per_split;
   const int kc1 = min(a.nchunks, kc0 + a.chunks_per_split);
   const int nstages = (kc1 - kc0 + KS - 1) / KS;
+  const int ph = ph_id(a);  // (upsample phase launches: grid.y)
 
   if (wave >= 4) {
     // ================================ loader ================================
@@ -346,8 +348,8 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
         const int p = mm - b * HoWo;
         const int oy = p / a.Wo;
         a_b[i] = b;
-        a_oy[i] = oy * a.stride - a.pad_lo;
-        a_ox[i] = (p - oy * a.Wo) * a.stride - a.pad_lo;
+        a_oy[i] = oy * a.stride - (a.ph_on ? 1 - (ph >> 1) : a.pad_lo);
+        a_ox[i] = (p - oy * a.Wo) * a.stride - (a.ph_on ? 1 - (ph & 1) : a.pad_lo);
       }
     }
     int cur_kc = kc0, cur_c0, cur_ky, cur_kx;
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
       const int rg = lw + 4 * i;
       const int row = rg * 16 + r16;
       b_ok[i] = (rg < BG) && (n0 + row < a.npad);
-      bp[i] = a.w + ((long)kc0 * a.npad + n0 + row) * 32 + chd * 8;
+      bp[i] = a.w + (long)ph * a.ph_wstride + ((long)kc0 * a.npad + n0 + row) * 32 + chd * 8;
     }
     const long wstep = (long)a.npad * 32;
 
@@ -565,7 +567,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
       for (int w = 1; w < 4; ++w) v += *(const f32x4*)(red + ((w * NF + f) * 64 + lane) * 4);
       return v;
     };
-    float* slab = a.partial ? a.partial + (long)blockIdx.z * a.M * a.npad : nullptr;
+    float* slab = a.partial ? a.partial + ((long)blockIdx.z * (a.ph_on ? 4 : 1) + ph) * a.M * a.npad : nullptr;
     if (slab) {
       for (int f = wave; f < NF; f += 4) {  // fragment f = (i, j) is finished by wave f % 4
         const int i = f / NI, j = f - i * NI;
@@ -741,7 +743,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
     return;
   }
   if (a.partial) {
-    float* slab = a.partial + (long)blockIdx.z * a.M * a.npad;
+    float* slab = a.partial + ((long)blockIdx.z * (a.ph_on ? 4 : 1) + ph) * a.M * a.npad;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = mw + i * 16 + lc;
@@ -773,8 +775,8 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmArgs a, in
   if (idx >= total) return;
   const int m = (int)(idx / nq);
   const int n = (int)(idx - (long)m * nq) * 4;
-  const long slab = (long)a.M * a.npad;
-  const float* p = a.partial + (long)m * a.npad + n;
+  const long slab = (long)a.M * a.npad * (a.ph_on ? 4 : 1);  // (phase launches: slabs [z][phase], grid.y = phase)
+  const float* p = a.partial + ((long)ph_id(a) * a.M + m) * a.npad + n;
   f32x4 v = {0, 0, 0, 0}, g = {0, 0, 0, 0};
   if (a.flags & UPK_F_GEGLU) {
     if (n & 32) return;  // gate columns are consumed by their value partner
@@ -1187,8 +1189,26 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   a.WL = a.ups ? 2 * a.WS : a.WS;
   a.ks = d->ksize;
   a.stride = d->stride;
+  a.ph_on = 0;
+  a.ph_wstride = 0;
+  static const bool ph_off = getenv("UPK_NO_PHASES") != nullptr;
+  const bool phases = d->w_phase && a.ups && d->ksize == 3 && d->stride == 1 && !(flags & UPK_F_PAD_ASYM) && !ph_off &&
+                      !d->x3 && !d->ln_colsum && !d->vt && !d->residual && !d->rowvec && !d->pc_enable &&
+                      !(flags & (UPK_F_GEGLU | UPK_F_OUT_NCHW_F32));
   const int pad = (d->ksize == 3) ? 1 : 0;
-  if (flags & UPK_F_PAD_ASYM) {
+  if (phases) {
+    // nearest 2x upsample + conv3x3 = four 2x2 convs on the low-resolution grid (4/9 of the MACs): output pixel
+    // (2y + py, 2x + px) sees low-resolution rows {y + py - 1, y + py} and columns {x + px - 1, x + px}
+    a.ph_on = 1;
+    a.ups = 0;
+    a.HL = a.HS;
+    a.WL = a.WS;
+    a.ks = 2;
+    a.pad_lo = 1;  // (the kernels take 1 - py / 1 - px)
+    a.Ho = a.HS;
+    a.Wo = a.WS;
+    a.w = (const f16*)d->w_phase;
+  } else if (flags & UPK_F_PAD_ASYM) {
     if (d->stride != 2 || d->ksize != 3) return upk_fail(ctx, UPK_ESHAPE, "conv: PAD_ASYM needs 3x3 s2");
     a.pad_lo = 0;
     a.Ho = (a.HL + 1 - 3) / 2 + 1;
@@ -1214,6 +1234,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   a.cpt = (a.c1 + a.c2) / 32;
   a.nchunks_main = a.ks * a.ks * a.cpt;
   a.nchunks = a.nchunks_main;
+  if (a.ph_on) a.ph_wstride = a.nchunks_main * a.npad * 32;
   if (d->x3) {
     if (d->c3 <= 0 || (d->c3 & 31) || d->c4 < 0 || (d->c4 & 31) || (d->c4 > 0 && !d->x4) || (d->ld3 & 7) ||
         (d->c4 && (d->ld4 & 7)))
@@ -1246,7 +1267,8 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   int best = -1, best_sk = 1;
   double best_t = 1e30;
   const int sk_cands[] = {1, 2, 3, 4, 6, 8, 9, 12, 16, 18};
-  const size_t slab = (size_t)a.M * a.npad * sizeof(float);
+  const int nph = a.ph_on ? 4 : 1;
+  const size_t slab = (size_t)a.M * a.npad * sizeof(float) * nph;
   const int want_cfg = ctx->cfg_override >= 0 ? ctx->cfg_override : (d->tune_cfg > 0 ? d->tune_cfg - 1 : -1);
   const int want_sk = ctx->splitk_override > 0 ? ctx->splitk_override : (d->tune_splitk > 0 ? d->tune_splitk : 0);
   for (int c = 0; c < kNumCfgs; ++c) {
@@ -1258,7 +1280,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
       if (want_sk > 0 && sk != want_sk) continue;
       if (a.ln_u && sk > 1) continue;
       if (sk > 1 && (slab * sk > ctx->ws_bytes || a.nchunks / sk < 4)) continue;
-      const double t = estimate(kCfgs[c], a.M, a.npad, a.nchunks, sk, ctx->num_cus, geglu);
+      const double t = estimate(kCfgs[c], a.M * nph, a.npad, a.nchunks, sk, ctx->num_cus, geglu);
       if (t < best_t) {
         best_t = t;
         best = c;
@@ -1282,7 +1304,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   // GroupNorm partials from the reduce pass (see igemm_reduce_gn_kernel)
   // ... or the whole GroupNorm from the reduce pass (igemm_reduce_gnapply_kernel)
   int ga_v = 0, ga_nv = 0;
-  if (d->gno_y && zdim > 1 && Epi::plain(a) && d->gn_groups > 0 && a.n_out % d->gn_groups == 0 && d->gno_gamma &&
+  if (d->gno_y && !a.ph_on && zdim > 1 && Epi::plain(a) && d->gn_groups > 0 && a.n_out % d->gn_groups == 0 && d->gno_gamma &&
       d->gno_beta) {
     const int cpg = a.n_out / d->gn_groups;
     // one workgroup per (sample, group) pays while a thread holds <= 2 vectors of 4 channels (the 4x4 / 8x8 levels:
@@ -1295,13 +1317,13 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     if (nv <= (v == 4 ? nv_max : (nv_max > 2 ? (v == 1 ? 32 : 8) : 0))) ga_v = v, ga_nv = nv;
   }
   const bool gn_apply = ga_v != 0;
-  const bool gn_fuse = !gn_apply && d->gn_stats_ws && zdim > 1 && Epi::plain(a) && !(a.n_out & 7) && a.n_out <= 2048 &&
+  const bool gn_fuse = !gn_apply && !a.ph_on && d->gn_stats_ws && zdim > 1 && Epi::plain(a) && !(a.n_out & 7) && a.n_out <= 2048 &&
                        d->gn_groups > 0 && d->gn_groups <= UPK_GN_GROUPS_MAX && a.n_out % d->gn_groups == 0 &&
                        !(a.ldy & 7) && (!a.res || !(a.ldr & 7));
   // ... or, without split-K, per-(M tile, channel) partials from the plain epilogue (Epi::tile_plain_cp and the
   // K-split kernels' epilogue): needs M tiles that lie inside one sample
   const int hw_out = a.Ho * a.Wo;
-  const bool gn_cp = d->gn_stats_ws && zdim == 1 && Epi::plain(a) && d->gn_groups > 0 &&
+  const bool gn_cp = !a.ph_on && d->gn_stats_ws && zdim == 1 && Epi::plain(a) && d->gn_groups > 0 &&
                      d->gn_groups <= UPK_GN_GROUPS_MAX && a.n_out % d->gn_groups == 0 && a.n_out <= 2048 &&
                      hw_out % BM == 0 && hw_out / BM <= UPK_GN_MAX_CHUNKS;
   if (gn_cp) {
@@ -1310,7 +1332,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     a.gn_hw = hw_out;
   }
   // LayerNorm row sums of the output for the consumer GEMM (Epi::tile_plain_lnr / the K-split kernels' epilogue)
-  if (d->ln_rows_out && zdim == 1 && Epi::plain(a) && !gn_cp && (c.wm * c.wn > 1 || c.nbuf > 0)) {
+  if (d->ln_rows_out && !a.ph_on && zdim == 1 && Epi::plain(a) && !gn_cp && (c.wm * c.wn > 1 || c.nbuf > 0)) {
     const int slots = a.tiles_n * c.wn;  // (K-split kernels: one slot per N tile)
     if (slots <= 8) {
       a.lnr_out = d->ln_rows_out;
@@ -1337,7 +1359,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   }
 #endif
   upk_prof_scope prof(ctx, UPK_CLS_IGEMM, stream);
-  dim3 grid(a.tiles_m * a.tiles_n, 1, zdim);
+  dim3 grid(a.tiles_m * a.tiles_n, nph, zdim);
   hipLaunchKernelGGL((a.ln_u && !a.lnr_in) ? c.fn_ln : (a.x3 ? c.fn_app : c.fn), grid, dim3(c.nbuf ? 512 : c.wm * c.wn * 64), 0, stream, a);
   int rc = upk_check_launch(ctx, "igemm");
   if (rc) return rc;
@@ -1375,7 +1397,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     rc = upk_check_launch(ctx, "igemm_reduce_gn");
   } else if (zdim > 1) {
     const long total = (long)a.M * (a.npad / 4);
-    hipLaunchKernelGGL(igemm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, zdim);
+    hipLaunchKernelGGL(igemm_reduce_kernel, dim3((unsigned)((total + 255) / 256), nph), dim3(256), 0, stream, a, zdim);
     rc = upk_check_launch(ctx, "igemm_reduce");
   }
   return rc;

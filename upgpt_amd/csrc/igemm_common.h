@@ -87,7 +87,20 @@ struct IgemmArgs {
                          // [slots][M][2], slot = (output column) / (columns per wave); nullptr: no
   const float* lnr_in;   // folded LayerNorm (ln_u) takes the row statistics from here ([lnr_slots][M][2]) instead of
   int lnr_slots;         // from the A fragments: any kernel family can run the GEMM
+  // ---- conv3x3 behind a nearest 2x upsample as four 2x2 convs on the low-resolution grid (include/upk.h w_phase):
+  // grid.y = phase (py, px) = (y >> 1, y & 1); phase weights at w + phase * ph_wstride, padding (1 - py, 1 - px),
+  // row m = (b, y, x) of the low-resolution grid is written to output pixel (2y + py, 2x + px)
+  int ph_on;
+  int ph_wstride;
 };
+
+// phase-mode helpers (uniform: blockIdx.y)
+__device__ __forceinline__ int ph_id(const IgemmArgs& a) { return a.ph_on ? (int)blockIdx.y : 0; }
+__device__ __forceinline__ unsigned ph_row(const IgemmArgs& a, unsigned mm) {  // output row of low-resolution row mm
+  const unsigned W = (unsigned)a.Wo;
+  const unsigned q = mm / W, x = mm - q * W, ph = blockIdx.y;
+  return (2u * q + (ph >> 1)) * 2u * W + 2u * x + (ph & 1u);
+}
 
 // 16-byte chunk swizzle for a [rows][4 chunks] fp16 tile (64 B rows).
 // ds_read_b128 is serviced in four 16-lane groups {0-3,12-15,20-27},{4-11,16-19,28-31},...
@@ -160,7 +173,7 @@ struct Epi {
     RowCtx r;
     r.ok = m < mlim;
     const int mm = r.ok ? m : 0;
-    r.y_off = (unsigned)mm * (unsigned)a.ldy;
+    r.y_off = (a.ph_on ? ph_row(a, (unsigned)mm) : (unsigned)mm) * (unsigned)a.ldy;
     r.res_off = (unsigned)mm * (unsigned)a.ldr;
     r.rv_off = 0;
     r.vt_off = 0;
@@ -321,7 +334,7 @@ struct Epi {
       const unsigned mm = r.ok ? (unsigned)m : 0u;
       r.rv_off = has_rv ? (unsigned)(st * a.rv_ss + (int)(mm / (unsigned)hw) * a.rv_bs) : 0u;
       r.res_off = (mm * (unsigned)a.ldr) & has_res;
-      r.y_off = mm * (unsigned)a.ldy;
+      r.y_off = (a.ph_on ? ph_row(a, mm) : mm) * (unsigned)a.ldy;
       return r;
     }
     __device__ __forceinline__ f32x4 rv4(const IgemmArgs& a, const Row& r, int n) const {

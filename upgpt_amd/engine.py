@@ -67,6 +67,7 @@ TUNE_CACHE = TuneCache(os.environ.get("UPGPT_TUNE_FILE") or None)
 # Off by default: parity-green, but inside the replayed forward it does not beat implicit GEMM + GroupNorm launch yet
 # (profiles/r02_pconv_*): 3.61 ms vs 3.52 ms per forward with the "auto" rule below.
 PCONV_MODE = os.environ.get("UPGPT_PCONV", "0")
+UPS_PHASES = os.environ.get("UPGPT_UPS_PHASES", "1") == "1"
 LN_ROWS = os.environ.get("UPGPT_LN_ROWS", "1") == "1"
 QPROJ_FUSE = os.environ.get("UPGPT_QPROJ_FUSE", "1") == "1"
 GN_REDUCE_APPLY = os.environ.get("UPGPT_GN_REDUCE_APPLY", "1") == "1"
@@ -101,7 +102,7 @@ class Act:
 
 class PW:
     """A packed weight: fp16 tiles + fp32 bias in packed row order."""
-    __slots__ = ("w", "n_pad", "bias", "n_out", "k_packed", "ksize", "n_real", "k_real", "ln_colsum", "k_append")
+    __slots__ = ("w", "n_pad", "bias", "n_out", "k_packed", "ksize", "n_real", "k_real", "ln_colsum", "k_append", "w_phase")
 
 
 class Packer:
@@ -151,6 +152,7 @@ class Packer:
         p.bias = None
         p.ln_colsum = None
         p.k_append = 0
+        p.w_phase = None
         b = None
         if bias:
             bs = [self.get(n + ".bias") for n in names]
@@ -160,6 +162,28 @@ class Packer:
             p.ln_colsum = rows_packed(w.half().float().sum(dim=1))
         if b is not None:
             p.bias = rows_packed(b)
+        return p
+
+    def add_upsample_phases(self, p, name):
+        """Phase weights of an Upsample conv (include/upk.h w_phase): nearest 2x + conv3x3 = four 2x2 convs on the
+        low-resolution grid; tap (ty, tx) of phase (py, px) = sum of the 3x3 taps that read the same low-resolution
+        pixel (summed in fp32, rounded to fp16 once)."""
+        w = self.get(name + ".weight").float().to(self.dev)
+        assert w.dim() == 4 and w.shape[-1] == 3 and w.shape[-2] == 3
+        taps = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}  # (phase bit, tap) -> 3x3 taps
+        parts = []
+        for py in (0, 1):
+            for px in (0, 1):
+                wp = torch.zeros(w.shape[0], w.shape[1], 2, 2, device=self.dev)
+                for ty in (0, 1):
+                    for tx in (0, 1):
+                        for ky in taps[(py, ty)]:
+                            for kx in taps[(px, tx)]:
+                                wp[:, :, ty, tx] += w[:, :, ky, kx]
+                packed, n_pad = self.ctx.pack_weight(wp.contiguous())
+                assert n_pad == p.n_pad
+                parts.append(packed.reshape(-1))
+        p.w_phase = torch.cat(parts).contiguous()
         return p
 
     def append_1x1(self, main, skip):
@@ -441,6 +465,9 @@ class Emitter:
         d.n_out, d.n_pad = pw.n_out, pw.n_pad
         if pw.bias is not None:
             d.bias = pw.bias.data_ptr()
+        phased = UPS_PHASES and bool(flags & L.F_UPSAMPLE2X) and pw.w_phase is not None and x2 is None
+        if phased:
+            d.w_phase = pw.w_phase.data_ptr()
         if residual is not None:
             d.residual = residual.t.data_ptr()
             d.ld_res = residual.ld
@@ -513,6 +540,8 @@ class Emitter:
                             vt is not None, ln_eps is not None and lnr is None, ka=d.c3 + d.c4)
         if use_pc:
             key += "_pc" + ("" if gn is None else "_gn%d" % int(bool(gn[3])))
+        if phased:
+            key += "_ph"
         self.convs.append((d, key))
         fn, h, ref = self.lib.upk_conv2d_nhwc_f16, self.hctx, C.byref(d)
         chk = self._chk
@@ -731,7 +760,7 @@ class PackedUNet:
             elif Lr.kind == "down":
                 w[n + ".op"] = pk.pack(n + ".op")
             elif Lr.kind == "up":
-                w[n + ".conv"] = pk.pack(n + ".conv")
+                w[n + ".conv"] = pk.add_upsample_phases(pk.pack(n + ".conv"), n + ".conv")
         norm("out.0")
         w["out.2"] = pk.pack("out.2")
         self.w, self.v = w, v
@@ -959,7 +988,7 @@ class PackedVAEDecoder:
                 w[n + ".qkv"] = pk.pack([d + ".q", d + ".k", d + ".v"], n_out=2 * Lr.ch)
                 w[n + ".proj_out"] = pk.pack(d + ".proj_out")
             elif Lr.kind == "upconv":
-                w[n] = pk.pack(d)
+                w[n] = pk.add_upsample_phases(pk.pack(d), d)
             elif Lr.kind == "norm_out":
                 norm(n)
         self.w, self.v = w, v
