@@ -22,6 +22,8 @@ SHAPES = {
     "c3_M512": (3, 896, 896, 8, 8, 0), "c3_M128": (3, 896, 896, 4, 4, 0), "k1_M512": (1, 896, 896, 8, 8, 0),
     "ff1_M2048": (1, 448, 3584, 16, 16, L.F_GEGLU), "c3_M2048": (3, 448, 448, 16, 16, 0),
     "ff1_M8192": (1, 224, 1792, 32, 32, L.F_GEGLU), "qkv_M8192": (1, 224, 768, 32, 32, 0), "ff2_M8192": (1, 896, 224, 32, 32, 0),
+    "v128": (3, 128, 128, 256, 256, 0), "v256": (3, 256, 256, 128, 128, 0), "v512": (3, 512, 512, 64, 64, 0),
+    "v512s": (3, 512, 512, 32, 32, 0), "v256_128": (3, 256, 128, 256, 256, 0),
     "c3_M8192": (3, 224, 224, 32, 32, 0), "k1_M8192": (1, 224, 224, 32, 32, 0), "c3_M8192_448": (3, 448, 224, 32, 32, 0),
 }
 
@@ -29,10 +31,11 @@ SHAPES = {
 def main():
     ctx = get_context(0)
     names = [a for a in sys.argv[1:] if a.split("+")[0] in SHAPES] or list(SHAPES)  # name[+gs][+rv][+res]
-    B, reps = 8, 16
+    B = 8
     ncfg = ctx.lib.upk_conv_num_configs()
     for name in names:
         base = name.split("+")[0]
+        reps = 16 if SHAPES[base][3] * SHAPES[base][4] <= 4096 else 3
         feats = name.split("+")[1:]
         ks, cin, cout, H, W, flags = SHAPES[base]
         g = torch.Generator().manual_seed(1)
@@ -41,7 +44,7 @@ def main():
         wbytes = K * cout * 2
         w = (torch.randn(cout, cin, ks, ks, generator=g) / math.sqrt(K)).to(DEV)
         wp, n_pad = ctx.pack_weight(w.contiguous())
-        ncold = max(2, int(600e6 // wbytes))
+        ncold = max(2, min(64, int(600e6 // wbytes)))
         wps = [wp.clone() for _ in range(ncold)]
         n_real = cout // 2 if flags & L.F_GEGLU else cout
         y = torch.zeros(B, H, W, n_real, device=DEV, dtype=torch.float16)
@@ -55,7 +58,7 @@ def main():
             name, ks, cin, cout, H, W, B * H * W, gf, wbytes / 1e6, ncold), flush=True)
         res = {}
         for cfg in range(ncfg):
-            for sk in (1, 2, 4, 8, 9):
+            for sk in ((1, 2, 4, 8, 9) if B * H * W <= 8192 else (1,)):
                 d = L.ConvDesc()
                 d.x1, d.c1, d.ld1 = x.data_ptr(), cin, cin
                 d.batch, d.in_h, d.in_w, d.ksize, d.stride = B, H, W, ks, 1

@@ -1075,6 +1075,8 @@ const CfgInfo kCfgs[] = {
     // 64-512 output rows; with 2 stages in flight each workgroup pays one HBM round trip per ~32 KB
     CFGW(2, 4, 2, 2, 2, 6), CFGW(4, 4, 2, 2, 1, 6), CFGW(2, 2, 2, 2, 2, 8), CFGW(2, 7, 4, 1, 1, 6),
     CFGW(1, 4, 4, 1, 2, 8), CFGW(4, 2, 2, 2, 2, 6),
+    // (256x128 / 128x256 tiles — 85 FLOP per filled byte against 64 — were tried for the VAE decoder's long convs:
+    // 128 accumulator registers + the plain / statistics epilogues spill 50-200 VGPRs at 2 waves per SIMD; not kept)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
