@@ -212,6 +212,11 @@ typedef struct upk_conv_desc {
    * the 3x3 taps (ky, kx) with (py + ky - 1) >> 1 == py + ty - 1 and likewise for x.  Plain epilogue only (bias ->
    * fp16 NHWC / fp32); w_packed stays the 3x3 weight (used when the launch cannot take the phase form). */
   const void* w_phase;
+  /* Row-block capacity of gn_stats_ws for the per-(row block, channel) partials of an unsplit launch (mode 2): 0 = 32
+   * (batch * 32 * 2 * max(n_pad, 32) floats); larger values (buffer: batch * cap * 2 * max(n_pad, 32) floats) let
+   * launches with many M tiles per sample — the VAE decoder's 64x64 ... 256x256 feature maps — leave their partials
+   * too; a consumer then folds them with upk_groupnorm_finalize_f32 before upk_groupnorm_apply_nhwc_f16 (mode 1). */
+  int32_t gn_stats_cap;
 } upk_conv_desc;
 
 /* Replaces F.conv2d (3x3 s1/s2 p1, 1x1) / F.linear call sites:
@@ -226,6 +231,12 @@ int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream)
  * {0, 1, 2, 3}, *nblk = row blocks per sample for mode 2; 3 = the reduce pass applies the GroupNorm itself (gno_*) and
  * leaves no statistics.  Nothing is enqueued. */
 int upk_conv_gn_fused(upk_ctx* ctx, const upk_conv_desc* d, int* mode, int* nblk);
+/* Folds per-(row block, channel) partials ([batch][nblk][2][ld], any nblk) into the per-(chunk, group) layout of
+ * upk_groupnorm_nhwc_f16's workspace (everything in chunk 0, zeros elsewhere), so that
+ * upk_groupnorm_apply_nhwc_f16(..., stats = ws, stats_mode = 1, ...) can follow: GroupNorm of a tensor whose producer
+ * conv ran more than 32 M tiles per sample, without a statistics pass over the tensor.  c channels, hw pixels. */
+int upk_groupnorm_finalize_f32(upk_ctx* ctx, const float* partials, int nblk, int ld, int batch, int hw, int c,
+                               int groups, float* ws, upk_stream stream);
 /* Number of column slots upk_conv2d_nhwc_f16(d) will fill in d->ln_rows_out (0: none — the launch splits K across workgroups or has no
  * plain epilogue).  Nothing is enqueued. */
 int upk_conv_ln_rows(upk_ctx* ctx, const upk_conv_desc* d, int* slots);

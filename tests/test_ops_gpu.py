@@ -1024,3 +1024,39 @@ def test_upsample_conv_as_four_phase_convs(ctx, B, C, N, H, W, sk, f32):
         outs.append(y)
     # the two forms differ only by the fp16 rounding of the summed taps
     check(outs[0], outs[1], tol=1e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,cin,cout,silu", [(64, 64, 64, 128, True), (96, 64, 32, 256, False), (128, 128, 32, 128, True)])
+def test_groupnorm_from_many_block_partials(ctx, H, W, cin, cout, silu):
+    """VAE-decoder-sized feature maps: the conv leaves per-(row block, channel) partials for more than 32 blocks per
+    sample (gn_stats_cap), upk_groupnorm_finalize_f32 folds them, the apply pass normalises without a statistics
+    pass (model.py:38-39, 82-121)."""
+    B = 2
+    x = rnd(B, cin, H, W)
+    w = rnd(cout, cin, 3, 3, scale=1 / math.sqrt(9 * cin))
+    b = rnd(cout, scale=0.1)
+    gamma, beta = rnd(cout, seed=3) * 0.5 + 1.0, rnd(cout, seed=4) * 0.3
+    y = torch.zeros(B, H, W, cout, device=DEV, dtype=torch.float16)
+    d = make_desc(ctx, nhwc16(x), w, b, y)
+    cap = H * W // 64
+    sws = torch.zeros(ctx.gn_stats_floats(B, d.n_pad, cap), device=DEV)
+    d.gn_stats_ws, d.gn_groups, d.gn_stats_cap = sws.data_ptr(), 32, cap
+    mode, nblk = ctx.conv_gn_fused(d)
+    assert mode == 2 and 32 < nblk <= cap, (mode, nblk)
+    ctx.conv(d)
+    ws = torch.zeros(ctx.groupnorm_ws_bytes(B, H * W) // 4 + 64, device=DEV)
+    ctx._chk(ctx.lib.upk_groupnorm_finalize_f32(ctx.h, sws.data_ptr(), nblk, d.n_pad, B, H * W, cout, 32, ws.data_ptr(),
+                                                ctx._s()))
+    yn = torch.zeros_like(y)
+    ctx._chk(ctx.lib.upk_groupnorm_apply_nhwc_f16(ctx.h, y.data_ptr(), cout, cout, None, 0, 0, B, H * W, 32,
+                                                  gamma.data_ptr(), beta.data_ptr(), 1e-6, int(silu), yn.data_ptr(), cout,
+                                                  ws.data_ptr(), 1, 0, 0, None, 0, 0, ctx._s()))
+    torch.cuda.synchronize()
+    ref = F.group_norm(y.float().permute(0, 3, 1, 2), 32, gamma, beta, 1e-6)
+    if silu:
+        ref = F.silu(ref)
+    check(yn.permute(0, 3, 1, 2), ref)
+    # without the capacity field the launch reports no by-product (33+ blocks do not fit the default buffer)
+    d.gn_stats_cap = 0
+    assert ctx.conv_gn_fused(d)[0] == 0

@@ -19,7 +19,7 @@ SYMBOLS = [
     "upk_pack_weight_f16", "upk_packed_weight_bytes", "upk_conv2d_nhwc_f16", "upk_gemm_f16",
     "upk_conv_autotune", "upk_conv_override", "upk_conv_num_configs", "upk_conv_config_name", "upk_conv_gn_fused",
     "upk_pconv_num_configs", "upk_pconv_config_name", "upk_pconv_supported", "upk_conv_ln_rows",
-    "upk_attention_f16", "upk_groupnorm_nhwc_f16", "upk_groupnorm_stats_nhwc_f16", "upk_groupnorm_chunks", "upk_groupnorm_apply_nhwc_f16", "upk_groupnorm_ws_bytes",
+    "upk_attention_f16", "upk_groupnorm_nhwc_f16", "upk_groupnorm_stats_nhwc_f16", "upk_groupnorm_chunks", "upk_groupnorm_apply_nhwc_f16", "upk_groupnorm_finalize_f32", "upk_groupnorm_ws_bytes",
     "upk_layernorm_f16", "upk_timestep_embed_f16",
     "upk_nchw_f32_to_nhwc_f16", "upk_nhwc_f16_to_nchw_f32", "upk_f32_to_f16", "upk_ddim_step_f32",
     "upk_ddim_step_cfg_f32", "upk_plms_step_f32", "upk_attention_causal_f16", "upk_attention_qproj_f16", "upk_embed_tokens_f16",
@@ -67,7 +67,7 @@ class ConvDesc(C.Structure):
         ("gno_gamma", C.c_void_p), ("gno_beta", C.c_void_p), ("gno_y", C.c_void_p), ("gno_eps", C.c_float),
         ("gno_silu", C.c_int32), ("gno_ld", C.c_int32), ("gno_skip_y", C.c_int32),
         ("ln_rows_out", C.c_void_p), ("ln_rows_in", C.c_void_p), ("ln_rows_slots", C.c_int32),
-        ("w_phase", C.c_void_p),
+        ("w_phase", C.c_void_p), ("gn_stats_cap", C.c_int32),
     ]
 
 
@@ -125,6 +125,7 @@ def load_library(path=None):
             "upk_groupnorm_apply_nhwc_f16": (C.c_int, [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp,
                                                        f32, i32, vp, i32, vp, i32, i32, i32, vp, i32, i32, vp]),
             "upk_conv_gn_fused": (C.c_int, [vp, C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+            "upk_groupnorm_finalize_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
             "upk_groupnorm_ws_bytes": (C.c_size_t, [i32, i32]),
             "upk_layernorm_f16": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, f32, vp, i32, vp]),
             "upk_timestep_embed_f16": (C.c_int, [vp, vp, i32, i32, f32, vp, i32, vp]),
@@ -246,9 +247,9 @@ class Context:
         self._chk(self.lib.upk_conv_gn_fused(self.h, C.byref(desc), C.byref(f), C.byref(n)))
         return f.value, n.value
 
-    def gn_stats_floats(self, batch, n_pad):
-        """Size (floats) of a upk_conv_desc.gn_stats_ws buffer."""
-        return batch * 32 * 2 * max(n_pad, 32)
+    def gn_stats_floats(self, batch, n_pad, cap=32):
+        """Size (floats) of a upk_conv_desc.gn_stats_ws buffer (cap = upk_conv_desc.gn_stats_cap row blocks)."""
+        return batch * max(32, cap) * 2 * max(n_pad, 32)
 
     def groupnorm_ws_bytes(self, batch, hw):
         return self.lib.upk_groupnorm_ws_bytes(batch, hw)

@@ -1327,7 +1327,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   const int hw_out = a.Ho * a.Wo;
   const bool gn_cp = !a.ph_on && d->gn_stats_ws && zdim == 1 && Epi::plain(a) && d->gn_groups > 0 &&
                      d->gn_groups <= UPK_GN_GROUPS_MAX && a.n_out % d->gn_groups == 0 && a.n_out <= 2048 &&
-                     hw_out % BM == 0 && hw_out / BM <= UPK_GN_MAX_CHUNKS;
+                     hw_out % BM == 0 && hw_out / BM <= (d->gn_stats_cap > UPK_GN_MAX_CHUNKS ? d->gn_stats_cap : UPK_GN_MAX_CHUNKS);
   if (gn_cp) {
     a.gn_cp = d->gn_stats_ws;
     a.gn_nblk = hw_out / BM;

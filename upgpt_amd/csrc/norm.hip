@@ -270,6 +270,48 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a, int rows_
   }
 }
 
+// Channel partials of a producer conv with many M tiles per sample -> the group partial layout of gn_stats_kernel
+// (chunk 0 holds the totals, the other chunks zero): one workgroup per (sample, group), fixed summation order.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* part, int nblk, int ld, int cpg, int groups,
+                                                          int nchunks, float* ws) {
+  __shared__ double red[2][4];
+  const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+  const float* p = part + (long)b * nblk * 2 * ld + g * cpg;
+  const int n = nblk * cpg;  // (block, channel) pairs of this group
+  double s1 = 0.0, s2 = 0.0;
+  for (int e0 = tid; e0 < n; e0 += 256 * 4) {
+    float v1[4], v2[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * 256;
+      const int k = e / cpg, c = e - k * cpg;
+      const bool on = e < n;
+      v1[u] = on ? p[(long)k * 2 * ld + c] : 0.f;
+      v2[u] = on ? p[(long)k * 2 * ld + ld + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s1 += (double)v1[u];
+      s2 += (double)v2[u];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    s1 += __shfl_xor(s1, o);
+    s2 += __shfl_xor(s2, o);
+  }
+  if ((tid & 63) == 0) {
+    red[0][tid >> 6] = s1;
+    red[1][tid >> 6] = s2;
+  }
+  __syncthreads();
+  if (tid < nchunks * 2) {
+    const int chunk = tid >> 1, which = tid & 1;
+    const double t = ((red[which][0] + red[which][1]) + red[which][2]) + red[which][3];
+    ws[((long)(b * nchunks + chunk) * groups + g) * 2 + which] = chunk == 0 ? (float)t : 0.f;
+  }
+}
+
 // One wave per row; the row lives in registers (d <= 2048), exact two-pass mean/variance.
 template <int VPL>  // 16-byte vectors per lane
 __global__ __launch_bounds__(256) void layernorm_kernel(const f16* x, int ldx, int rows, int d, const float* gamma,
@@ -382,6 +424,9 @@ static int gn_launch(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* 
                       (c2 != 0 && (!stats_ws2 || cp_ld2 < c2 || cp_nblk2 <= 0 || cp_nblk2 > GN_MAX_CHUNKS))))
     return upk_fail(ctx, UPK_EINVAL, "groupnorm apply: channel partials need stats_ld >= channels and 0 < nblk <= %d for "
                     "every source", GN_MAX_CHUNKS);
+  static const bool fold1 = getenv("UPK_GN_FOLD1") && atoi(getenv("UPK_GN_FOLD1"));  // dev: timing bound of a free partial fold (WRONG results)
+  if (fold1 && a.cp_nblk > 1) a.cp_nblk = 1;
+  if (fold1 && a.cp_nblk2 > 1) a.cp_nblk2 = 1;
   upk_prof_scope prof(ctx, UPK_CLS_GN, stream);
   int rc = UPK_OK;
   if (with_stats) {
@@ -451,4 +496,19 @@ extern "C" int upk_layernorm_f16(upk_ctx* ctx, const void* x, int ldx, int rows,
   else
     hipLaunchKernelGGL((layernorm_kernel<4>), grid, block, 0, stream, xp, ldx, rows, d, gamma, beta, eps, yp, ldy);
   return upk_check_launch(ctx, "layernorm");
+}
+
+extern "C" int upk_groupnorm_finalize_f32(upk_ctx* ctx, const float* partials, int nblk, int ld, int batch, int hw, int c,
+                                          int groups, float* ws, upk_stream stream_) {
+  if (!ctx) return UPK_EINVAL;
+  if (!partials || !ws) return upk_fail(ctx, UPK_EINVAL, "groupnorm finalize: null pointer");
+  if (nblk <= 0 || batch <= 0 || hw <= 0 || c <= 0 || groups <= 0 || groups > GN_GROUPS_MAX || c % groups || ld < c)
+    return upk_fail(ctx, UPK_EINVAL, "groupnorm finalize: bad shape");
+  int nchunks, ppc;
+  upk_gn_chunking(hw, &nchunks, &ppc);
+  hipStream_t stream = (hipStream_t)stream_;
+  upk_prof_scope prof(ctx, UPK_CLS_GN, stream);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, batch), dim3(256), 0, stream, partials, nblk, ld, c / groups, groups,
+                     nchunks, ws);
+  return upk_check_launch(ctx, "gn_finalize");
 }

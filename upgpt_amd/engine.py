@@ -67,6 +67,10 @@ TUNE_CACHE = TuneCache(os.environ.get("UPGPT_TUNE_FILE") or None)
 # Off by default: parity-green, but inside the replayed forward it does not beat implicit GEMM + GroupNorm launch yet
 # (profiles/r02_pconv_*): 3.61 ms vs 3.52 ms per forward with the "auto" rule below.
 PCONV_MODE = os.environ.get("UPGPT_PCONV", "0")
+# GroupNorm statistics of the VAE decoder's tensors as conv by-products (gn_stats_cap + upk_groupnorm_finalize_f32):
+# measured neutral (8.29 vs 8.29 ms per decode) — the statistics pass runs at 5.6 TB/s since round 2, the channel
+# partials cost the 200-us convs 2-3 % and a 32-block fold per apply workgroup more than the pass it replaces — off
+VAE_GN_BYPRODUCT = os.environ.get("UPGPT_VAE_GN_BYPRODUCT", "0") == "1" or os.environ.get("UPGPT_PCONV", "0") != "0"
 UPS_PHASES = os.environ.get("UPGPT_UPS_PHASES", "1") == "1"
 LN_ROWS = os.environ.get("UPGPT_LN_ROWS", "1") == "1"
 QPROJ_FUSE = os.environ.get("UPGPT_QPROJ_FUSE", "1") == "1"
@@ -300,6 +304,8 @@ class Emitter:
             if d.pc_enable:
                 continue  # (patch-kernel launches pick their tile configuration themselves)
             ent = cache.get(key)
+            if ent is None and not tune_missing and key.endswith("_gs"):
+                ent = cache.get(key[:-3])  # (statistics by-product armed on a shape that was tuned without it)
             if ent is None and tune_missing:
                 cfg, sk, best_us, dflt_us = self.ctx.conv_autotune(d, reps or int(os.environ.get("UPGPT_TUNE_REPS", "5")))
                 ent = cache.put(key, cfg, sk, best_us, dflt_us)
@@ -621,8 +627,9 @@ class Emitter:
             d = act.gn_src[0]
             if not d.gn_stats_ws:  # arm the producer and rename its tuning key
                 ci = act.gn_src[1]
-                sws = self.alloc(self.ctx.gn_stats_floats(act.B, d.n_pad), dtype=torch.float32)
-                d.gn_stats_ws, d.gn_groups = sws.data_ptr(), 32
+                cap = max(32, (act.H * act.W) // 64)  # (more than 32 row blocks per sample: folded by a finalize launch)
+                sws = self.alloc(self.ctx.gn_stats_floats(act.B, d.n_pad, cap), dtype=torch.float32)
+                d.gn_stats_ws, d.gn_groups, d.gn_stats_cap = sws.data_ptr(), 32, cap
                 assert self.convs[ci][0] is d
                 self.convs[ci] = (d, self.convs[ci][1] + "_gs")
                 act.gn_src = (d, ci, sws)
@@ -647,6 +654,7 @@ class Emitter:
             # unsplit epilogue (every source of a concat must have them); decided by the tuned / cost-model choice
             # at the time the program runs or is captured
             fused_fn, apply_fn = self.lib.upk_conv_gn_fused, self.lib.upk_groupnorm_apply_nhwc_f16
+            fin_fn = self.lib.upk_groupnorm_finalize_f32
             mine = None
             if GN_REDUCE_APPLY and x2 is None and not armed[0][0].gno_y:
                 # a producer that splits K normalises in its reduce pass (include/upk.h gno_*): this op then launches nothing
@@ -661,6 +669,13 @@ class Emitter:
                     chk(fused_fn(h, C.byref(d), C.byref(mode), C.byref(nblk)))
                     info.append((mode.value if mode.value != 3 or d is mine else 0, nblk.value, d.n_pad, sws.data_ptr()))
                 if len(info) == 1 and info[0][0] == 3:
+                    return
+                if len(info) == 1 and info[0][0] == 2 and info[0][1] > 32:
+                    # long feature maps (VAE decoder): the producer's channel partials are folded per (sample, group)
+                    # first — one small launch instead of a statistics pass over the tensor
+                    m, nb, ld, p1 = info[0]
+                    chk(fin_fn(h, p1, nb, ld, x1.B, x1.H * x1.W, x1.C, 32, ws.data_ptr(), s))
+                    chk(apply_fn(h, *a, ws.data_ptr(), 1, 0, 0, None, 0, 0, s))
                     return
                 if len(info) == 1 and info[0][0]:
                     m, nb, ld, p1 = info[0]
@@ -1019,12 +1034,12 @@ class VAEDecodePlan(Emitter):
         for Lr in a.decoder:
             n = Lr.name
             if Lr.kind == "conv":
-                x = self.conv(P, x, W_[n])
+                x = self.conv(P, x, W_[n], gn_stats=VAE_GN_BYPRODUCT)
             elif Lr.kind == "resnet":
-                h1 = self.conv(P, x, W_[n + ".conv1"], gn=(*V_[n + ".norm1"], 1e-6, True, self.gn_ws), gn_stats=PCONV_ON)
+                h1 = self.conv(P, x, W_[n + ".conv1"], gn=(*V_[n + ".norm1"], 1e-6, True, self.gn_ws), gn_stats=VAE_GN_BYPRODUCT)
                 sk = self.conv(P, x, W_[n + ".nin_shortcut"]) if Lr.cin != Lr.cout else x
                 x = self.conv(P, h1, W_[n + ".conv2"], residual=sk, gn=(*V_[n + ".norm2"], 1e-6, True, self.gn_ws),
-                              gn_stats=PCONV_ON)
+                              gn_stats=VAE_GN_BYPRODUCT)
             elif Lr.kind == "attn":
                 c, HW = Lr.ch, x.H * x.W
                 xn = self.groupnorm(P, x, *V_[n + ".norm"], 1e-6, False, self.gn_ws)
@@ -1036,7 +1051,7 @@ class VAEDecodePlan(Emitter):
                 ao = Act(self.alloc(x.M, c), x.B, x.H, x.W, c)
                 self.attention(P, qk.t, 2 * c, HW * 2 * c, qk.t[:, c:], 2 * c, HW * 2 * c, vt, vt_ld, ao.t, c, HW * c,
                                x.B, 1, HW, HW, c, int(c) ** -0.5)
-                x = self.conv(P, ao, W_[n + ".proj_out"], residual=x)
+                x = self.conv(P, ao, W_[n + ".proj_out"], residual=x, gn_stats=VAE_GN_BYPRODUCT)
             elif Lr.kind == "upconv":
                 x = self.conv(P, x, W_[n], flags=L.F_UPSAMPLE2X)
             elif Lr.kind == "norm_out":
@@ -1113,12 +1128,12 @@ class VAEEncodePlan(Emitter):
         for Lr in a.encoder:
             n = Lr.name
             if Lr.kind == "conv":
-                x = self.conv(P, x, W_[n])
+                x = self.conv(P, x, W_[n], gn_stats=VAE_GN_BYPRODUCT)
             elif Lr.kind == "resnet":
-                h1 = self.conv(P, x, W_[n + ".conv1"], gn=(*V_[n + ".norm1"], 1e-6, True, self.gn_ws), gn_stats=PCONV_ON)
+                h1 = self.conv(P, x, W_[n + ".conv1"], gn=(*V_[n + ".norm1"], 1e-6, True, self.gn_ws), gn_stats=VAE_GN_BYPRODUCT)
                 sk = self.conv(P, x, W_[n + ".nin_shortcut"]) if Lr.cin != Lr.cout else x
                 x = self.conv(P, h1, W_[n + ".conv2"], residual=sk, gn=(*V_[n + ".norm2"], 1e-6, True, self.gn_ws),
-                              gn_stats=PCONV_ON)
+                              gn_stats=VAE_GN_BYPRODUCT)
             elif Lr.kind == "attn":
                 c, HW = Lr.ch, x.H * x.W
                 xn = self.groupnorm(P, x, *V_[n + ".norm"], 1e-6, False, self.gn_ws)
