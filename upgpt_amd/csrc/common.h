@@ -106,14 +106,16 @@ static inline int upk_check_launch(upk_ctx* ctx, const char* what) {
   return UPK_OK;
 }
 
-__device__ __forceinline__ float upk_silu(float v) { return v / (1.0f + __expf(-v)); }
+// (v_rcp_f32, 1 ulp, instead of an IEEE division: the ~10-instruction div sequence per element was most of the VALU
+// work of the GroupNorm apply passes; results are rounded to fp16 right after)
+__device__ __forceinline__ float upk_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 // exact (erf) GELU, attention.py:44 (F.gelu default)
 // erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, far below the fp16 output step): branch-free,
 // ~14 instructions, where the device library's erff is a multi-branch piecewise evaluation — the GEGLU
 // epilogue calls this 4x per fragment and is the longest epilogue on the path.
 __device__ __forceinline__ float upk_erf(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));  // (1 ulp; __frcp_rn is a full division sequence)
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);

@@ -245,7 +245,7 @@ struct Epi {
     }
     if (flags & UPK_F_QUICKGELU) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = v[k] / (1.0f + __expf(-1.702f * v[k]));
+      for (int k = 0; k < 4; ++k) v[k] = v[k] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v[k]));
     }
     if (to_vt) {
       const int cc = n - a.vt_from;  // = h * dhead + d  ->  row (h*dhead + d) of this sample's V^T

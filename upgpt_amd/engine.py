@@ -589,7 +589,7 @@ class Emitter:
                     mode, nblk = C.c_int(0), C.c_int(0)
                     chk(fused_fn(h, C.byref(dsrc), C.byref(mode), C.byref(nblk)))
                     info.append((mode.value, nblk.value, dsrc.n_pad, sws.data_ptr()))
-                if info and all(i[0] == 2 for i in info):
+                if info and all(i[0] == 2 and i[1] <= 32 for i in info):
                     d.gni_mode = 2
                     d.gni_stats1, d.gni_nblk1, d.gni_ld1 = info[0][3], info[0][1], info[0][2]
                     if len(info) == 2:
@@ -680,7 +680,7 @@ class Emitter:
                 if len(info) == 1 and info[0][0]:
                     m, nb, ld, p1 = info[0]
                     chk(apply_fn(h, *a, p1, m, nb, ld, None, 0, 0, s))
-                elif len(info) == 2 and info[0][0] == 2 and info[1][0] == 2:
+                elif len(info) == 2 and info[0][0] == 2 and info[1][0] == 2 and max(info[0][1], info[1][1]) <= 32:
                     chk(apply_fn(h, *a, info[0][3], 2, info[0][1], info[0][2], info[1][3], info[1][1], info[1][2], s))
                 else:
                     chk(fn(h, *a, ws.data_ptr(), s))
