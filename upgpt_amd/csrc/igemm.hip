@@ -778,6 +778,7 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmArgs a, in
   const long slab = (long)a.M * a.npad * (a.ph_on ? 4 : 1);  // (phase launches: slabs [z][phase], grid.y = phase)
   const float* p = a.partial + ((long)ph_id(a) * a.M + m) * a.npad + n;
   f32x4 v = {0, 0, 0, 0}, g = {0, 0, 0, 0};
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   if (a.flags & UPK_F_GEGLU) {
     if (n & 32) return;  // gate columns are consumed by their value partner
     for (int z = 0; z < splitk; ++z) {
@@ -785,7 +786,14 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmArgs a, in
       g += *(const f32x4*)(p + z * slab + 32);
     }
   } else {
-    for (int z = 0; z < splitk; ++z) v += *(const f32x4*)(p + z * slab);
+    // four slabs in flight (a one-load-per-iteration loop with a runtime trip count runs at the latency of a load)
+    for (int z0 = 0; z0 < splitk; z0 += 4) {
+      f32x4 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = z0 + u < splitk ? *(const f32x4*)(p + (long)(z0 + u) * slab) : z4;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v += t[u];  // (slab order, as before)
+    }
   }
   IgemmArgs b = a;
   b.partial = nullptr;
