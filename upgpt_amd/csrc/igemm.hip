@@ -77,9 +77,9 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
       a_oy[i] = 0;
       a_ox[i] = mm;
     } else {
-      const int b = mm / HoWo;
+      const int b = div_hw(a, mm, HoWo);
       const int p = mm - b * HoWo;
-      const int oy = p / a.Wo;
+      const int oy = div_w(a, p);
       a_b[i] = b;
       a_oy[i] = oy * a.stride - (a.ph_on ? 1 - (ph >> 1) : a.pad_lo);
       a_ox[i] = (p - oy * a.Wo) * a.stride - (a.ph_on ? 1 - (ph & 1) : a.pad_lo);
@@ -344,9 +344,9 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
         a_oy[i] = 0;
         a_ox[i] = mm;
       } else {
-        const int b = mm / HoWo;
+        const int b = div_hw(a, mm, HoWo);
         const int p = mm - b * HoWo;
-        const int oy = p / a.Wo;
+        const int oy = div_w(a, p);
         a_b[i] = b;
         a_oy[i] = oy * a.stride - (a.ph_on ? 1 - (ph >> 1) : a.pad_lo);
         a_ox[i] = (p - oy * a.Wo) * a.stride - (a.ph_on ? 1 - (ph & 1) : a.pad_lo);
@@ -1230,6 +1230,15 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   }
   a.M = a.B * a.Ho * a.Wo;
   if (a.M <= 0) return upk_fail(ctx, UPK_EINVAL, "conv: empty output");
+  {
+    auto lg2 = [](int v) {
+      int s = 0;
+      while ((1 << s) < v) ++s;
+      return (1 << s) == v ? s : -1;
+    };
+    a.sh_hw = lg2(a.Ho * a.Wo);
+    a.sh_w = lg2(a.Wo);
+  }
   a.linear = (a.ks == 1 && a.stride == 1 && !a.ups) ? 1 : 0;
   a.ln_u = d->ln_colsum;
   a.ln_eps = d->ln_eps;

@@ -92,13 +92,20 @@ struct IgemmArgs {
   // row m = (b, y, x) of the low-resolution grid is written to output pixel (2y + py, 2x + px)
   int ph_on;
   int ph_wstride;
+  // log2 of Ho*Wo / Wo when they are powers of two (the 256x256 workloads: 32, 16, 8, 4), else -1: the im2col row
+  // decode and the epilogue's sample index become shifts instead of two ~20-instruction integer divisions per row,
+  // on the path to the first DMA of every 3x3 launch
+  int sh_hw, sh_w;
 };
+
+__device__ __forceinline__ int div_hw(const IgemmArgs& a, int m, int hw) { return a.sh_hw >= 0 ? m >> a.sh_hw : m / hw; }
+__device__ __forceinline__ int div_w(const IgemmArgs& a, int p) { return a.sh_w >= 0 ? p >> a.sh_w : p / a.Wo; }
 
 // phase-mode helpers (uniform: blockIdx.y)
 __device__ __forceinline__ int ph_id(const IgemmArgs& a) { return a.ph_on ? (int)blockIdx.y : 0; }
 __device__ __forceinline__ unsigned ph_row(const IgemmArgs& a, unsigned mm) {  // output row of low-resolution row mm
   const unsigned W = (unsigned)a.Wo;
-  const unsigned q = mm / W, x = mm - q * W, ph = blockIdx.y;
+  const unsigned q = a.sh_w >= 0 ? mm >> a.sh_w : mm / W, x = mm - q * W, ph = blockIdx.y;
   return (2u * q + (ph >> 1)) * 2u * W + 2u * x + (ph & 1u);
 }
 
@@ -180,7 +187,7 @@ struct Epi {
     r.nchw_off = 0;
     if (a.rowvec || (a.flags & UPK_F_OUT_NCHW_F32)) {
       const int hw = a.Ho * a.Wo;
-      const int b = mm / hw;
+      const int b = div_hw(a, mm, hw);
       const int p = mm - b * hw;
       const int st = (a.rowvec && a.step) ? *a.step : 0;
       r.rv_off = (unsigned)(st * a.rv_ss + b * a.rv_bs);
@@ -332,7 +339,7 @@ struct Epi {
       Row r;
       r.ok = m < mlim;
       const unsigned mm = r.ok ? (unsigned)m : 0u;
-      r.rv_off = has_rv ? (unsigned)(st * a.rv_ss + (int)(mm / (unsigned)hw) * a.rv_bs) : 0u;
+      r.rv_off = has_rv ? (unsigned)(st * a.rv_ss + div_hw(a, (int)mm, hw) * a.rv_bs) : 0u;
       r.res_off = (mm * (unsigned)a.ldr) & has_res;
       r.y_off = (a.ph_on ? ph_row(a, mm) : mm) * (unsigned)a.ldy;
       return r;
