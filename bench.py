@@ -97,7 +97,7 @@ def gathered(step_fn):
     return lambda: D.all_gather_images(step_fn())
 
 
-def kernel_class_profile(model, wl, reps=10):
+def kernel_class_profile(model, wl, reps=20):
     """Per-kernel-class GPU time of one UNet forward, measured live under the SAME conditions
     as the timed region (HIP-graph replay): the forward's launch list is captured once in full
     and once without the class, both replayed `reps` times between HIP events recorded on the
@@ -131,13 +131,25 @@ def kernel_class_profile(model, wl, reps=10):
                 return e0.elapsed_time(e1) / reps
 
         torch.cuda.synchronize()
-        full = timed(())
+        timed(())  # (clocks settle)
         names = {"igemm": ("igemm_k1", "igemm_k3"), "attention": ("attention",), "groupnorm": ("groupnorm",),
                  "layernorm": ("layernorm",)}
         out = {}
+        fulls = []
         for k, classes in names.items():
             n = sum(1 for c in body.cls if c in classes)
-            out[k] = {"ms_per_fwd": full - timed(classes), "launches_per_fwd": n}
+            if n == 0:
+                out[k] = {"ms_per_fwd": 0.0, "launches_per_fwd": 0}
+                continue
+            # full and ablated replays back to back, three times: the median difference is insensitive to the clock
+            # drift of a warming GPU (a single full-vs-ablated pair taken minutes apart was off by +-0.09 ms)
+            diffs = []
+            for _ in range(3):
+                f = timed(())
+                fulls.append(f)
+                diffs.append(f - timed(classes))
+            out[k] = {"ms_per_fwd": sorted(diffs)[1], "launches_per_fwd": n}
+        full = sorted(fulls)[len(fulls) // 2]
         # GPU kernels per class of one eager pass (a split-K launch = kernel + reduce pass, a GroupNorm with its own
         # statistics = 2): counted by the library (upk_kernel_launches)
         for k, classes in list(names.items()) + [("all", None)]:
