@@ -1,3 +1,5 @@
+"""Which producer launches of the UNet plan leave LayerNorm row sums (upk_conv_ln_rows), by shape and tuned tile
+configuration (dev tool)."""
 import contextlib, io, os, sys, ctypes as C, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import upgpt_amd
