@@ -52,12 +52,11 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
   const int lc = lane & 15;
 
   // tile coordinates: consecutive blocks walk M first (they share the weight tile in L2)
-  const int tile = blockIdx.x;
-  const int tn = tile / a.tiles_m;
-  const int tm = tile - tn * a.tiles_m;
+  int tm, tn, zs;
+  if (!tile_map(a, tm, tn, zs)) return;  // (whole workgroup, before any barrier)
   const int m0 = tm * BM;
   const int n0 = tn * BN;
-  const int kc0 = blockIdx.z * a.chunks_per_split;
+  const int kc0 = zs * a.chunks_per_split;
   const int kc1 = min(a.nchunks, kc0 + a.chunks_per_split);
 
   const int ph = ph_id(a);  // (upsample phase launches: grid.y)
@@ -236,7 +235,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
     return;
   }
   if (a.partial) {
-    float* slab = a.partial + ((long)blockIdx.z * (a.ph_on ? 4 : 1) + ph) * a.M * a.npad;  // uniform base
+    float* slab = a.partial + ((long)zs * (a.ph_on ? 4 : 1) + ph) * a.M * a.npad;  // uniform base
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = mw + i * 16 + lc;
@@ -312,12 +311,11 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = blockIdx.x;
-  const int tn = tile / a.tiles_m;
-  const int tm = tile - tn * a.tiles_m;
+  int tm, tn, zs;
+  if (!tile_map(a, tm, tn, zs)) return;  // (whole workgroup, before any barrier)
   const int m0 = tm * BM;
   const int n0 = tn * BN;
-  const int kc0 = blockIdx.z * a.chunks_per_split;
+  const int kc0 = zs * a.chunks_per_split;
   const int kc1 = min(a.nchunks, kc0 + a.chunks_per_split);
   const int nstages = (kc1 - kc0 + KS - 1) / KS;
   const int ph = ph_id(a);  // (upsample phase launches: grid.y)
@@ -567,7 +565,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
       for (int w = 1; w < 4; ++w) v += *(const f32x4*)(red + ((w * NF + f) * 64 + lane) * 4);
       return v;
     };
-    float* slab = a.partial ? a.partial + ((long)blockIdx.z * (a.ph_on ? 4 : 1) + ph) * a.M * a.npad : nullptr;
+    float* slab = a.partial ? a.partial + ((long)zs * (a.ph_on ? 4 : 1) + ph) * a.M * a.npad : nullptr;
     if (slab) {
       for (int f = wave; f < NF; f += 4) {  // fragment f = (i, j) is finished by wave f % 4
         const int i = f / NI, j = f - i * NI;
@@ -743,7 +741,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
     return;
   }
   if (a.partial) {
-    float* slab = a.partial + ((long)blockIdx.z * (a.ph_on ? 4 : 1) + ph) * a.M * a.npad;
+    float* slab = a.partial + ((long)zs * (a.ph_on ? 4 : 1) + ph) * a.M * a.npad;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = mw + i * 16 + lc;
@@ -1378,7 +1376,38 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   }
 #endif
   upk_prof_scope prof(ctx, UPK_CLS_IGEMM, stream);
+  // XCD-aware tile order (tile_map): choose the pm x pn split of the 8 XCDs that minimises the bytes pulled over the
+  // fabric — weights by pm XCDs, activations by pn — against the default order (tile index round-robin), measured at
+  // 3.5-7x the algorithmic bytes on the 16x16 ... 4x4 levels (scripts/pmc_fetch.sh)
+  a.xm_pm = 0;
+  a.xm_z = zdim;
+  static const int xmap = getenv("UPK_XCD_MAP") ? atoi(getenv("UPK_XCD_MAP")) : 1;
   dim3 grid(a.tiles_m * a.tiles_n, nph, zdim);
+  if (xmap) {
+    const long units = (long)a.tiles_n * zdim;
+    const double Ab = (double)a.B * a.HS * a.WS * (a.c1 + a.c2) * 2.0 + (double)a.M * (a.c3 + a.c4) * 2.0;
+    const double Wb = (double)a.nchunks * 32.0 * a.npad * 2.0;
+    auto gcd = [](int x, int y) { while (y) { const int t = x % y; x = y; y = t; } return x; };
+    const double cur = Wb * (a.tiles_m < 8 ? a.tiles_m : 8) +
+                       Ab * (double)(units < 8 / gcd(a.tiles_m, 8) ? units : 8 / gcd(a.tiles_m, 8));
+    double best = cur * 0.85;  // (the default order unless the gain is clear)
+    const int pms[4] = {1, 2, 4, 8};
+    for (int pm : pms) {
+      const int pn = 8 / pm;
+      if (pm > a.tiles_m || pn > units) continue;
+      const int mi = cdiv(a.tiles_m, pm), nj = (int)((units + pn - 1) / pn);
+      if ((double)8 * mi * nj > 1.2 * (double)a.tiles_m * units) continue;  // too many idle slots
+      const double c = Wb * pm + Ab * pn;
+      if (c < best) {
+        best = c;
+        a.xm_pm = pm;
+        a.xm_pn = pn;
+        a.xm_mi = mi;
+        a.xm_nj = nj;
+      }
+    }
+    if (a.xm_pm) grid = dim3(8 * a.xm_mi * a.xm_nj, nph, 1);
+  }
   hipLaunchKernelGGL((a.ln_u && !a.lnr_in) ? c.fn_ln : (a.x3 ? c.fn_app : c.fn), grid, dim3(c.nbuf ? 512 : c.wm * c.wn * 64), 0, stream, a);
   int rc = upk_check_launch(ctx, "igemm");
   if (rc) return rc;

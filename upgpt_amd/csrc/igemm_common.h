@@ -96,7 +96,32 @@ struct IgemmArgs {
   // decode and the epilogue's sample index become shifts instead of two ~20-instruction integer divisions per row,
   // on the path to the first DMA of every 3x3 launch
   int sh_hw, sh_w;
+  // ---- XCD-aware tile order (xm_pm > 0): workgroup w runs on XCD w % 8; the 8 XCDs form a pm x pn grid over
+  // (M tiles) x (N tile, K split) units, so that an operand is fetched over the fabric by pm (weights) / pn
+  // (activations) XCDs instead of by every XCD that happens to hold one of its tiles.  mi x nj = tiles x units per
+  // XCD; grid.x = 8 * mi * nj, surplus workgroups exit
+  int xm_pm, xm_pn, xm_mi, xm_nj, xm_z;
 };
+
+// (tm, tn, split index) of this workgroup; false: nothing to do (XCD-aware grids are padded)
+__device__ __forceinline__ bool tile_map(const IgemmArgs& a, int& tm, int& tn, int& zs) {
+  if (a.xm_pm == 0) {
+    const int tile = blockIdx.x;
+    tn = tile / a.tiles_m;
+    tm = tile - tn * a.tiles_m;
+    zs = blockIdx.z;
+    return true;
+  }
+  const int w = blockIdx.x;
+  const int xcd = w & 7, l = w >> 3;
+  const int xi = xcd / a.xm_pn, xj = xcd - xi * a.xm_pn;
+  const int ul = l / a.xm_mi, tl = l - ul * a.xm_mi;  // M tiles fastest: neighbours in time share the weight slice
+  tm = xi * a.xm_mi + tl;
+  const int u = xj * a.xm_nj + ul;
+  zs = u / a.tiles_n;
+  tn = u - zs * a.tiles_n;
+  return tm < a.tiles_m && zs < a.xm_z;
+}
 
 __device__ __forceinline__ int div_hw(const IgemmArgs& a, int m, int hw) { return a.sh_hw >= 0 ? m >> a.sh_hw : m / hw; }
 __device__ __forceinline__ int div_w(const IgemmArgs& a, int p) { return a.sh_w >= 0 ? p >> a.sh_w : p / a.Wo; }
