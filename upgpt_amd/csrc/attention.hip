@@ -177,10 +177,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
-  const int bh = blockIdx.y;
+  const int bh = blockIdx.x;  // (all query blocks of one (sample, head) on one XCD: its K / V cross the fabric once)
   const int b = bh / a.heads;
   const int h = bh - b * a.heads;
-  const int q0 = (blockIdx.x * 4 + wave) * 16 * QT;
+  const int q0 = (blockIdx.y * 4 + wave) * 16 * QT;
   if (q0 >= a.nq) return;
   const f16* kbase = a.k + b * a.kbs + h * D + g * 8;
   const f16* vbase = a.vt + ((long)(b * a.heads + h) * D + c) * a.vt_ld + g * 4;
@@ -384,10 +384,10 @@ __global__ __launch_bounds__(256) void attn_lds_kernel(const AttnArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
-  const int bh = blockIdx.y;
+  const int bh = blockIdx.x;  // (see attn_kernel)
   const int b = bh / a.heads;
   const int h = bh - b * a.heads;
-  const int q0 = (blockIdx.x * 4 + wave) * 16 * QT;
+  const int q0 = (blockIdx.y * 4 + wave) * 16 * QT;
   const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
   bool q_ok[QT];
@@ -538,7 +538,9 @@ static int attention_impl(upk_ctx* ctx, const void* q, int ldq, long long qbs, c
   // two 16-query groups per wave when there are enough queries to keep every CU busy
   static const int qt_env = getenv("UPK_ATTN_QT") ? atoi(getenv("UPK_ATTN_QT")) : 0;  // dev
   const int qt = qt_env ? qt_env : ((d <= 128 && (long)((n_q + 127) / 128) * batch * heads >= 2L * ctx->num_cus) ? 2 : 1);
-  dim3 grid((n_q + 64 * qt - 1) / (64 * qt), batch * heads), block(256);
+  // grid.x = (sample, head): workgroups go to XCDs round-robin by linear index, so with batch * heads a multiple of 8
+  // every query block of a (sample, head) lands on the same XCD and K / V are fetched over the fabric once, not 8 times
+  dim3 grid(batch * heads, (n_q + 64 * qt - 1) / (64 * qt)), block(256);
   upk_prof_scope prof(ctx, UPK_CLS_ATTN, stream);
   // long self-attention sequences: K / V^T tiles shared through LDS (whole 64-key tiles only)
   static const bool lds_off = getenv("UPK_ATTN_DIRECT") != nullptr;
