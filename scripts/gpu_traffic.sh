@@ -15,17 +15,20 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == c]
     ig = [r for r in rows if "igemm" in r["Kernel_Name"] or "pconv" in r["Kernel_Name"]]
     main = [r for r in ig if "reduce" not in r["Kernel_Name"]]
+    # the library's own per-forward kernels (the run also builds the model: weight packing, torch fills, rocBLAS)
+    fwd = [r for r in rows if any(t in r["Kernel_Name"] for t in ("igemm", "pconv", "attn_", "gn_", "layernorm_kernel", "ddim_step"))]
     raw[c] = dict(kb_igemm=sum(float(r["Counter_Value"]) for r in ig), launches=len(main),
-                  kb_all=sum(float(r["Counter_Value"]) for r in rows))
+                  kb_all=sum(float(r["Counter_Value"]) for r in fwd))
 L = raw["FETCH_SIZE"]["launches"]
 fetch, write = raw["FETCH_SIZE"]["kb_igemm"] / L, raw["WRITE_SIZE"]["kb_igemm"] / L
 print(json.dumps({
     "round": 2, "commit": sys.argv[2],
     "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python scripts/fwd_replay.py 32 32 %d (scripts/gpu_traffic.sh)" % N,
-    "kernel_class": "igemm_ws_kernel<*> + igemm_kernel<*> + igemm_reduce[_gn]_kernel (+ pconv_kernel<*> when enabled); per conv/GEMM launch incl. its reduce pass",
+    "kernel_class": "igemm_ws_kernel<*> + igemm_kernel<*> + igemm_reduce[_gn|_gnapply]_kernel (+ pconv_kernel<*> when enabled); per conv/GEMM launch incl. its reduce pass",
     "launches": L, "fetch_size_kb_per_launch_raw": fetch, "write_size_kb_per_launch_raw": write,
     "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE as reported; KB -> x1024; Infinity-Cache hits are included (fabric-side counters)",
     "bytes_per_launch": (2 * fetch + write) * 1024.0,
-    "all_kernels_bytes_per_forward": (2 * raw["FETCH_SIZE"]["kb_all"] + raw["WRITE_SIZE"]["kb_all"]) * 1024.0 / (N + 1),
+    "all_kernels_bytes_per_forward": (2 * raw["FETCH_SIZE"]["kb_all"] + raw["WRITE_SIZE"]["kb_all"]) * 1024.0 / N,
+    "all_kernels_note": "conv/GEMM + attention + GroupNorm + LayerNorm + sampler-step kernels of the %d replayed forwards (plus the ~40 step-invariant prep launches of the run); model-setup kernels (weight packing, fills) excluded" % N,
 }, indent=1))
 PY
