@@ -1381,15 +1381,20 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   // 3.5-7x the algorithmic bytes on the 16x16 ... 4x4 levels (scripts/pmc_fetch.sh)
   a.xm_pm = 0;
   a.xm_z = zdim;
-  static const int xmap = getenv("UPK_XCD_MAP") ? atoi(getenv("UPK_XCD_MAP")) : 1;
+  static const int xmap = getenv("UPK_XCD_MAP") ? atoi(getenv("UPK_XCD_MAP")) : 2;  // 0 off, 1 without the 3x3 halo term, 2 default
   dim3 grid(a.tiles_m * a.tiles_n, nph, zdim);
   if (xmap) {
     const long units = (long)a.tiles_n * zdim;
     const double Ab = (double)a.B * a.HS * a.WS * (a.c1 + a.c2) * 2.0 + (double)a.M * (a.c3 + a.c4) * 2.0;
     const double Wb = (double)a.nchunks * 32.0 * a.npad * 2.0;
     auto gcd = [](int x, int y) { while (y) { const int t = x % y; x = y; y = t; } return x; };
+    // 3x3 convs: an M tile of r image rows also reads 2 halo rows; scattered over the XCDs every tile fetches its halo
+    // itself ((r + 2) / r of the activations), a contiguous run of mi tiles per XCD shares all but its two outer rows
+    const bool halo = xmap > 1 && a.ks == 3 && a.stride == 1 && !a.ups && !a.ph_on && BM >= a.Wo;
+    const double rows = halo ? (double)BM / a.Wo : 1.0;
+    const double h_def = halo ? (rows + 2.0) / rows : 1.0;
     const double cur = Wb * (a.tiles_m < 8 ? a.tiles_m : 8) +
-                       Ab * (double)(units < 8 / gcd(a.tiles_m, 8) ? units : 8 / gcd(a.tiles_m, 8));
+                       Ab * h_def * (double)(units < 8 / gcd(a.tiles_m, 8) ? units : 8 / gcd(a.tiles_m, 8));
     double best = cur * 0.85;  // (the default order unless the gain is clear)
     const int pms[4] = {1, 2, 4, 8};
     for (int pm : pms) {
@@ -1397,7 +1402,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
       if (pm > a.tiles_m || pn > units) continue;
       const int mi = cdiv(a.tiles_m, pm), nj = (int)((units + pn - 1) / pn);
       if ((double)8 * mi * nj > 1.2 * (double)a.tiles_m * units) continue;  // too many idle slots
-      const double c = Wb * pm + Ab * pn;
+      const double c = Wb * pm + Ab * pn * (halo ? (rows * mi + 2.0) / (rows * mi) : 1.0);
       if (c < best) {
         best = c;
         a.xm_pm = pm;
