@@ -20,19 +20,23 @@ REPS = int(os.environ.get("INSITU_REPS", "12"))
 TOPK = int(os.environ.get("INSITU_TOPK", "14"))
 
 VAE = os.environ.get("INSITU_VAE", "0") == "1"  # tune the VAE decoder (B = 8, latent HxW) instead of the UNet forward
+KIND = os.environ.get("INSITU_KIND", "bbox")     # "upscale": the upscale UNet (3 + 3 channels, 86 tokens)
+BATCH = int(os.environ.get("INSITU_B", "8"))     # 16 = the classifier-free-guidance pass over [uncond ; cond]
 with contextlib.redirect_stdout(io.StringIO()):
-    model = upgpt_amd.build_model("bbox")
+    model = upgpt_amd.build_model(KIND, overrides={"image_size": [H, W]}) if KIND == "upscale" else upgpt_amd.build_model("bbox")
 synth.fill_module_(model); model = model.cuda()
 unet = model.model.diffusion_model
-inp = synth.synth_inputs(8, (H, W), 4, 87, 768, seed=0, text_only=True)
+NTOK, CH = (86, 3) if KIND == "upscale" else (87, 4)
+inp = (synth.synth_inputs(BATCH, (H, W), 3, 86, 768, seed=0, concat_channels=3) if KIND == "upscale"
+       else synth.synth_inputs(BATCH, (H, W), 4, 87, 768, seed=0, text_only=True))
 if VAE:
     vp = model.first_stage_model._decode_plan(8, H, W, 0.18215)
     vp.z.copy_(torch.randn(8, 4, H, W))
-pl = unet.plan(8, H, W, 87, 50, "sampler")
-pl.load_x_nchw(inp["x_T"].cuda(), 0, 0); pl.load_x_nchw(inp["c_concat"].cuda(), 4, pl.cin_pad)
+pl = unet.plan(BATCH, H, W, NTOK, 50, "sampler")
+pl.load_x_nchw(inp["x_T"].cuda(), 0, 0); pl.load_x_nchw(inp["c_concat"].cuda(), CH, pl.cin_pad)
 pl.load_context(inp["c_crossattn"].cuda()); pl.t_rows.copy_(torch.arange(981, 0, -20, dtype=torch.float32)[:50])
 pl.prep.run()
-st = SamplerState(pl, 4); st.x.copy_(inp["x_T"].cuda()); st.coefs.fill_(0.5)
+st = SamplerState(pl, CH); st.x.copy_(inp["x_T"].cuda()); st.coefs.fill_(0.5)
 ctx = pl.ctx
 ncfg = ctx.lib.upk_conv_num_configs()
 
