@@ -1060,3 +1060,33 @@ def test_groupnorm_from_many_block_partials(ctx, H, W, cin, cout, silu):
     # without the capacity field the launch reports no by-product (33+ blocks do not fit the default buffer)
     d.gn_stats_cap = 0
     assert ctx.conv_gn_fused(d)[0] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,cin,cout,ks", [(8, 8, 8, 128, 256, 3), (8, 16, 16, 64, 448, 1), (4, 4, 4, 256, 896, 3)])
+def test_conv_xcd_aware_tile_order_visits_every_tile(ctx, B, H, W, cin, cout, ks):
+    """Grids large enough for the XCD-aware tile order (IgemmArgs::xm_*: padded grid, (M tiles) x (N tile, K split) units
+    dealt to a pm x pn arrangement of the 8 XCDs): every configuration x split-K must still write every output tile
+    exactly as F.conv2d does (a skipped or doubled tile shows as zeros / a wrong split-K sum)."""
+    x = rnd(B, cin, H, W)
+    w = rnd(cout, cin, ks, ks, scale=1 / math.sqrt(ks * ks * cin))
+    b = rnd(cout, scale=0.1)
+    ref = F.conv2d(x.half().float(), w.half().float(), b, padding=ks // 2)
+    xn = nhwc16(x)
+    ran = 0
+    try:
+        for cfg in range(ctx.lib.upk_conv_num_configs()):
+            for sk in (1, 2, 4, 8):
+                y = torch.full((B, H, W, cout), float("nan"), device=DEV, dtype=torch.float16)
+                ctx.conv_override(cfg, sk)
+                try:
+                    ctx.conv(make_desc(ctx, xn, w, b, y))
+                except L.UpkError:
+                    continue
+                torch.cuda.synchronize()
+                assert torch.isfinite(y).all(), (cfg, sk)
+                check(y.permute(0, 3, 1, 2), ref)
+                ran += 1
+    finally:
+        ctx.conv_override(-1, 0)
+    assert ran >= 60
