@@ -39,6 +39,8 @@ pl.prep.run()
 st = SamplerState(pl, CH); st.x.copy_(inp["x_T"].cuda()); st.coefs.fill_(0.5)
 ctx = pl.ctx
 ncfg = ctx.lib.upk_conv_num_configs()
+names = [ctx.lib.upk_conv_config_name(i).decode() for i in range(ncfg)]
+ONLY = os.environ.get("INSITU_ONLY", "")
 
 
 def replay_ms():
@@ -97,7 +99,15 @@ for key in sorted(groups, key=share, reverse=True):
     d0 = ds[0]
     start = (d0.tune_cfg - 1, d0.tune_splitk) if d0.tune_cfg > 0 else None
     sks = sorted({1, 2, 3, 4, 6, 8, 9} | ({start[1]} if start else set()))
-    cands = [(c, s) for c in range(ncfg) for s in sks if feasible(d0, c, s)]
+    if ONLY:  # e.g. INSITU_ONLY=as: only the A-stationary family's configurations (second slot = passes per workgroup)
+        if d0.ksize != 1:
+            continue
+        cands = [(c, s) for c in range(ncfg) if names[c].startswith(ONLY) for s in (1, 2, 3, 4, 6, 8, 12, 16)
+                 if feasible(d0, c, s)]
+        if not cands:
+            continue
+    else:
+        cands = [(c, s) for c in range(ncfg) for s in sks if feasible(d0, c, s)]
     # keep the candidates the single-launch tuner ranks near the top (plus the current choice)
     timed = []
     if len(cands) > TOPK:

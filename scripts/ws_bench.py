@@ -24,6 +24,9 @@ SHAPES = {
     "ff1_M8192": (1, 224, 1792, 32, 32, L.F_GEGLU), "qkv_M8192": (1, 224, 768, 32, 32, 0), "ff2_M8192": (1, 896, 224, 32, 32, 0),
     "v128": (3, 128, 128, 256, 256, 0), "v256": (3, 256, 256, 128, 128, 0), "v512": (3, 512, 512, 64, 64, 0),
     "v512s": (3, 512, 512, 32, 32, 0), "v256_128": (3, 256, 128, 256, 256, 0),
+    "qkv_M2048": (1, 448, 1536, 16, 16, 0), "ff2_M2048": (1, 1792, 448, 16, 16, 0), "ff2a_M8192": (1, 1120, 224, 32, 32, 0),
+    "ff2a_M2048": (1, 2240, 448, 16, 16, 0), "to_out_M8192": (1, 256, 224, 32, 32, 0), "to_out_M2048": (1, 512, 448, 16, 16, 0),
+    "ff1_M128": (1, 896, 7168, 4, 4, L.F_GEGLU), "qkv_M128": (1, 896, 3072, 4, 4, 0),
     "c3_M8192": (3, 224, 224, 32, 32, 0), "k1_M8192": (1, 224, 224, 32, 32, 0), "c3_M8192_448": (3, 448, 224, 32, 32, 0),
 }
 
@@ -33,6 +36,7 @@ def main():
     names = [a for a in sys.argv[1:] if a.split("+")[0] in SHAPES] or list(SHAPES)  # name[+gs][+rv][+res]
     B = 8
     ncfg = ctx.lib.upk_conv_num_configs()
+    only = [v.split(":") for v in os.environ.get("UPK_WS_ONLY", "").split(",") if v]  # e.g. as4x2p7:4,2x4x2x2k2w3:1
     for name in names:
         base = name.split("+")[0]
         reps = 16 if SHAPES[base][3] * SHAPES[base][4] <= 4096 else 3
@@ -58,7 +62,15 @@ def main():
             name, ks, cin, cout, H, W, B * H * W, gf, wbytes / 1e6, ncold), flush=True)
         res = {}
         for cfg in range(ncfg):
-            for sk in ((1, 2, 4, 8, 9) if B * H * W <= 8192 else (1,)):
+            cname = ctx.lib.upk_conv_config_name(cfg).decode()
+            is_as = cname.startswith("as")
+            if only and cname not in [o[0] for o in only]:
+                continue
+            if is_as and ks != 1:
+                continue
+            for sk in ((1, 2, 3, 4, 6, 8, 12, 16) if is_as else (1, 2, 4, 8, 9) if B * H * W <= 8192 else (1,)):
+                if only and [cname, str(sk)] not in only:
+                    continue
                 d = L.ConvDesc()
                 d.x1, d.c1, d.ld1 = x.data_ptr(), cin, cin
                 d.batch, d.in_h, d.in_w, d.ksize, d.stride = B, H, W, ks, 1

@@ -105,16 +105,24 @@ def test_conv_all_configs_and_splitk(ctx):
     xn = nhwc16(x)
     ncfg = ctx.lib.upk_conv_num_configs()
     assert ncfg >= 8
+    ran = 0
     try:
         for cfg in range(ncfg):
+            name = ctx.lib.upk_conv_config_name(cfg).decode()
             for sk in (1, 2, 3):
                 y = torch.zeros(B, H, W, cout, device=DEV, dtype=torch.float16)
                 ctx.conv_override(cfg, sk)
-                ctx.conv(make_desc(ctx, xn, w, b, y))
+                try:
+                    ctx.conv(make_desc(ctx, xn, w, b, y))
+                except L.UpkError:
+                    assert name.startswith("as"), name  # (only the A-stationary family refuses a 3x3: it is 1x1-only)
+                    continue
                 torch.cuda.synchronize()
                 check(y.permute(0, 3, 1, 2), ref)
+                ran += 1
     finally:
         ctx.conv_override(-1, 0)
+    assert ran >= 3 * 62
 
 
 @pytest.mark.parametrize("ks,c,c3,c4,cout,hw", [(3, 64, 96, 32, 224, (12, 10)), (3, 96, 64, 0, 64, (8, 8)),

@@ -9,6 +9,7 @@ import os
 import threading
 
 import torch
+from ._check import require
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UPK_LIB") or os.path.join(_HERE, "libupk.so")  # (UPK_LIB: dev builds)
@@ -145,7 +146,7 @@ def load_library(path=None):
             "upk_prof_enable": (C.c_int, [vp, i32]),
             "upk_prof_collect": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
         }
-        assert sorted(protos) == sorted(SYMBOLS)
+        require(sorted(protos) == sorted(SYMBOLS), "ctypes prototypes and SYMBOLS differ", RuntimeError)
         for name, (res, args) in protos.items():
             fn = getattr(lib, name)  # AttributeError if the .so does not export it
             fn.restype = res
@@ -284,7 +285,7 @@ class Context:
 
     def pack_weight(self, w, row_map=None, n_rows=None, col_map=None, cin_packed=None):
         """fp32 [O,I,kh,kw] or [O,I] CUDA tensor -> packed fp16 tensor, (n_pad)."""
-        assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
+        require(w.is_cuda and w.dtype == torch.float32 and w.is_contiguous(), "pack_weight: w must be a contiguous fp32 CUDA tensor", TypeError)
         if w.dim() == 2:
             cout, cin = w.shape
             kh = kw = 1
@@ -298,7 +299,7 @@ class Context:
         out = torch.empty(self.lib.upk_packed_weight_bytes(n_rows, cin_packed, kh, kw) // 2, dtype=torch.float16,
                           device=w.device)
         for m in (row_map, col_map):
-            assert m is None or (m.is_cuda and m.dtype == torch.int32 and m.is_contiguous())
+            require(m is None or (m.is_cuda and m.dtype == torch.int32 and m.is_contiguous()), "pack_weight: row_map / col_map must be contiguous int32 CUDA tensors", TypeError)
         self._chk(self.lib.upk_pack_weight_f16(self.h, w.data_ptr(), cout, cin, kh, kw, _ptr(row_map), n_rows,
                                                _ptr(col_map), cin_packed, out.data_ptr(), self._s()))
         return out, n_pad

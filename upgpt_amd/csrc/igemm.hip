@@ -1128,8 +1128,11 @@ double estimate(const CfgInfo& c, int M, int npad, int nchunks, int splitk, int 
 
 }  // namespace
 
-extern "C" int upk_conv_num_configs(void) { return kNumCfgs; }
+// configurations kNumCfgs .. kNumCfgs + astat_num_configs() - 1 are the A-stationary family (astat.hip); for those the
+// "split-K" slot of the tuning pair means output-column passes per workgroup (0 = fill the chip once)
+extern "C" int upk_conv_num_configs(void) { return kNumCfgs + astat_num_configs(); }
 extern "C" const char* upk_conv_config_name(int cfg) {
+  if (cfg >= kNumCfgs) return astat_config_name(cfg - kNumCfgs);
   return (cfg >= 0 && cfg < kNumCfgs) ? kCfgs[cfg].name : "?";
 }
 extern "C" int upk_conv_override(upk_ctx* ctx, int cfg, int splitk) {
@@ -1288,7 +1291,16 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   const size_t slab = (size_t)a.M * a.npad * sizeof(float) * nph;
   const int want_cfg = ctx->cfg_override >= 0 ? ctx->cfg_override : (d->tune_cfg > 0 ? d->tune_cfg - 1 : -1);
   const int want_sk = ctx->splitk_override > 0 ? ctx->splitk_override : (d->tune_splitk > 0 ? d->tune_splitk : 0);
-  for (int c = 0; c < kNumCfgs; ++c) {
+  AsPlan aspl;
+  const bool is_as = want_cfg >= kNumCfgs;
+  if (is_as) {
+    if (!astat_plan(ctx, a, want_cfg - kNumCfgs, want_sk, &aspl) || (want_sk > 1 && want_sk > aspl.npass))
+      return upk_fail(ctx, UPK_ESHAPE, "conv: A-stationary configuration %s (passes per workgroup %d) does not fit this launch",
+                      astat_config_name(want_cfg - kNumCfgs), want_sk);
+    best = want_cfg;
+    best_sk = 1;
+  }
+  for (int c = 0; c < kNumCfgs && !is_as; ++c) {
     if (want_cfg >= 0 && c != want_cfg) continue;
     // folded LayerNorm: row statistics come from the M x N-split wave-specialised kernels, whole K in one block
     if (a.ln_u && !a.lnr_in && !kCfgs[c].fn_ln) continue;
@@ -1311,10 +1323,10 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
                       slab * want_sk, ctx->ws_bytes);
     return upk_fail(ctx, UPK_ESHAPE, "conv: no kernel configuration fits (geglu=%d)", (int)geglu);
   }
-  const CfgInfo& c = kCfgs[best];
-  const int BM = c.mi * 16 * c.wm, BN = c.ni * 16 * c.wn;
+  const CfgInfo& c = kCfgs[is_as ? 0 : best];  // (not used by the A-stationary family beyond this block)
+  const int BM = is_as ? aspl.bm : c.mi * 16 * c.wm, BN = is_as ? aspl.pw * aspl.ppw : c.ni * 16 * c.wn;
   a.tiles_m = cdiv(a.M, BM);
-  a.tiles_n = cdiv(a.npad, BN);
+  a.tiles_n = is_as ? aspl.tiles_n : cdiv(a.npad, BN);
   a.chunks_per_split = cdiv(a.nchunks, best_sk);
   const int zdim = cdiv(a.nchunks, a.chunks_per_split);
   a.partial = (zdim > 1) ? (float*)ctx->ws : nullptr;
@@ -1331,7 +1343,10 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     const long nvec = (long)a.Ho * a.Wo * (cpg / v);
     const int nv = (int)((nvec + 255) / 256);
     static const int nv_max = getenv("UPK_GNAPPLY_NVMAX") ? atoi(getenv("UPK_GNAPPLY_NVMAX")) : 2;
-    if (nv <= (v == 4 ? nv_max : (nv_max > 2 ? (v == 1 ? 32 : 8) : 0))) ga_v = v, ga_nv = nv;
+    // (never more vectors per thread than the widest instantiation below covers: <4, 8>, <2, 8>, <1, 32>)
+    const int nv_inst = v == 1 ? 32 : 8;
+    const int nv_lim = v == 4 ? (nv_max < nv_inst ? nv_max : nv_inst) : (nv_max > 2 ? nv_inst : 0);
+    if (nv <= nv_lim) ga_v = v, ga_nv = nv;
   }
   const bool gn_apply = ga_v != 0;
   const bool gn_fuse = !gn_apply && !a.ph_on && d->gn_stats_ws && zdim > 1 && Epi::plain(a) && !(a.n_out & 7) && a.n_out <= 2048 &&
@@ -1349,8 +1364,9 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     a.gn_hw = hw_out;
   }
   // LayerNorm row sums of the output for the consumer GEMM (Epi::tile_plain_lnr / the K-split kernels' epilogue)
-  if (d->ln_rows_out && !a.ph_on && zdim == 1 && Epi::plain(a) && !gn_cp && (c.wm * c.wn > 1 || c.nbuf > 0)) {
-    const int slots = a.tiles_n * c.wn;  // (K-split kernels: one slot per N tile)
+  if (d->ln_rows_out && !a.ph_on && zdim == 1 && Epi::plain(a) && !gn_cp && (is_as || c.wm * c.wn > 1 || c.nbuf > 0)) {
+    // (K-split kernels: one slot per N tile; A-stationary: one per 16 * NI columns of its single pass, else none)
+    const int slots = is_as ? (aspl.npass == 1 ? cdiv(a.npad, astat_config_ni(best - kNumCfgs) * 16) : 99) : a.tiles_n * c.wn;
     if (slots <= 8) {
       a.lnr_out = d->ln_rows_out;
       if (lnr_slots) *lnr_slots = slots;
@@ -1369,7 +1385,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
       if (launch_no == atoi(tgt)) {
         a.flags |= ABL_TIMELINE;
         fprintf(stderr, "[timeline] launch %d: M=%d npad=%d nchunks=%d ks=%d cfg=%s(%d) splitk=%d flags=%x res=%d rowvec=%d\n", launch_no,
-                a.M, a.npad, a.nchunks, a.ks, kCfgs[best].name, best, zdim, flags, a.res != nullptr, a.rowvec != nullptr);
+                a.M, a.npad, a.nchunks, a.ks, upk_conv_config_name(best), best, zdim, flags, a.res != nullptr, a.rowvec != nullptr);
       }
       ++launch_no;
     }
@@ -1417,6 +1433,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     }
     if (a.xm_pm) grid = dim3(8 * a.xm_mi * a.xm_nj, nph, 1);
   }
+  if (is_as) return astat_launch(ctx, a, best - kNumCfgs, aspl, grid, stream);
   hipLaunchKernelGGL((a.ln_u && !a.lnr_in) ? c.fn_ln : (a.x3 ? c.fn_app : c.fn), grid, dim3(c.nbuf ? 512 : c.wm * c.wn * 64), 0, stream, a);
   int rc = upk_check_launch(ctx, "igemm");
   if (rc) return rc;
@@ -1551,7 +1568,7 @@ extern "C" int upk_conv_autotune(upk_ctx* ctx, const upk_conv_desc* d, upk_strea
   int bc = -1, bs = 1;
   if (rc == UPK_OK) {
     const int sks[] = {1, 2, 3, 4, 6, 8, 9, 12, 16, 18};
-    for (int c = 0; c < kNumCfgs; ++c)
+    for (int c = 0; c < upk_conv_num_configs(); ++c)
       for (int sk : sks) {
         float us = 0.f;
         if (time_one(c, sk, &us) != UPK_OK) continue;  // infeasible candidate

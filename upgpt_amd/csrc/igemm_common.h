@@ -101,6 +101,9 @@ struct IgemmArgs {
   // (activations) XCDs instead of by every XCD that happens to hold one of its tiles.  mi x nj = tiles x units per
   // XCD; grid.x = 8 * mi * nj, surplus workgroups exit
   int xm_pm, xm_pn, xm_mi, xm_nj, xm_z;
+  // ---- A-stationary family (astat.hip): a workgroup keeps its BM x K activation tile in LDS and walks passes
+  // [tn * as_ppw, min(as_npass, (tn + 1) * as_ppw)) of 8 waves x NI x 16 output columns; tiles_n = N super tiles
+  int as_ppw, as_npass;
 };
 
 // (tm, tn, split index) of this workgroup; false: nothing to do (XCD-aware grids are padded)
@@ -331,7 +334,7 @@ struct Epi {
     return !(a.flags & (UPK_F_GEGLU | UPK_F_SILU | UPK_F_QUICKGELU | UPK_F_OUT_F32 | UPK_F_OUT_NCHW_F32)) && !a.vt &&
            !(a.n_out & 3);
   }
-  static __device__ __forceinline__ bool plain_geglu(const IgemmArgs& a) {
+  static __host__ __device__ __forceinline__ bool plain_geglu(const IgemmArgs& a) {
     return (a.flags & (UPK_F_GEGLU | UPK_F_SILU | UPK_F_QUICKGELU | UPK_F_OUT_F32 | UPK_F_OUT_NCHW_F32)) == UPK_F_GEGLU &&
            !a.vt &&
            !a.rowvec && !a.res && !(a.n_out & 3);
@@ -605,6 +608,16 @@ struct Epi {
   }
 };
 
+
+// astat.hip: the A-stationary family (configurations kNumCfgs .. of upk_conv_config_name)
+struct AsPlan {
+  int bm, pw, npass, ppw, tiles_m, tiles_n, lds_bytes;
+};
+int astat_num_configs();
+const char* astat_config_name(int c);
+int astat_config_ni(int c);
+bool astat_plan(const upk_ctx* ctx, const IgemmArgs& a, int c, int ppw_req, AsPlan* pl);
+int astat_launch(upk_ctx* ctx, IgemmArgs& a, int c, const AsPlan& pl, dim3 grid, hipStream_t stream);
 
 // pconv.hip: runs the launch on the A-stationary patch kernel when the shape is inside its domain
 int pconv_run(upk_ctx* ctx, const upk_conv_desc* d, IgemmArgs& a, hipStream_t stream, bool launch, int* gn_fused,

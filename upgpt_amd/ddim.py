@@ -12,6 +12,7 @@ per step from Python (ddim.py:140-203).
 import numpy as np
 import torch
 
+from ._check import require
 from .schedule import (ddim_coefficient_table, extract_into_tensor, make_ddim_sampling_parameters,
                        make_ddim_timesteps)
 
@@ -41,7 +42,7 @@ class DDIMSampler(object):
                                                   num_ddim_timesteps=ddim_num_steps,
                                                   num_ddpm_timesteps=self.ddpm_num_timesteps, verbose=verbose)
         acp = self.model.alphas_cumprod
-        assert acp.shape[0] == self.ddpm_num_timesteps, "alphas have to be defined for each timestep"
+        require(acp.shape[0] == self.ddpm_num_timesteps, "alphas have to be defined for each timestep", ValueError)
         f32 = lambda x: torch.as_tensor(x).clone().detach().to(torch.float32).to(self.model.device)
         acp_cpu = acp.detach().cpu()
         self.register_buffer("betas", f32(self.model.betas))
@@ -125,8 +126,7 @@ class DDIMSampler(object):
             if c_concat is not None:
                 ncat = c_concat.shape[1]
                 plan.load_x_nchw(c_concat, C, plan.cin_pad)
-            assert C + ncat == unet.in_channels, "latent %d + concat %d != UNet in_channels %d" % (
-                C, ncat, unet.in_channels)
+            require(C + ncat == unet.in_channels, lambda: "latent %d + concat %d != UNet in_channels %d" % ( C, ncat, unet.in_channels), ValueError)
             order = np.arange(S)[::-1].copy()  # loop order: descending DDIM index
             plan.t_rows.copy_(torch.as_tensor(np.asarray(timesteps)[order].astype(np.float32)))
             plan.load_context(c_cross)
@@ -198,7 +198,7 @@ class DDIMSampler(object):
             index = total_steps - i - 1
             ts = torch.full((b,), int(step), device=device, dtype=torch.long)
             if mask is not None:
-                assert x0 is not None
+                require(x0 is not None, "mask given without x0", ValueError)
                 img_orig = self.model.q_sample(x0, ts)
                 img = img_orig * mask + (1. - mask) * img
             noise = None
@@ -247,7 +247,7 @@ class DDIMSampler(object):
             e_t_uncond, e_t = self.model.apply_model(x_in, t_in, c_in).chunk(2)
             e_t = e_t_uncond + unconditional_guidance_scale * (e_t - e_t_uncond)
         if score_corrector is not None:
-            assert self.model.parameterization == "eps"
+            require(self.model.parameterization == "eps", "classifier-free guidance / score correction needs an eps-parameterised model", NotImplementedError)
             e_t = score_corrector.modify_score(self.model, e_t, x, t, c, **corrector_kwargs)
 
         if quantize_denoised:

@@ -23,6 +23,7 @@ from .config import count_params, instantiate_from_config, to_plain
 from .ddim import DDIMSampler
 from .ema import LitEma
 from .schedule import extract_into_tensor, make_beta_schedule
+from ._check import require
 
 
 def disabled_train(self, mode=True):
@@ -36,7 +37,7 @@ class DiffusionWrapper(nn.Module):
         super().__init__()
         self.diffusion_model = instantiate_from_config(diff_model_config)
         self.conditioning_key = conditioning_key
-        assert self.conditioning_key in [None, "concat", "crossattn", "hybrid", "adm"]
+        require(self.conditioning_key in [None, "concat", "crossattn", "hybrid", "adm"], "unknown conditioning_key %r" % (self.conditioning_key,), ValueError)
 
     def forward(self, x, t, c_concat: list = None, c_crossattn: list = None):
         key = self.conditioning_key
@@ -107,8 +108,14 @@ class DDPM(nn.Module):
             raise AssertionError('currently only supporting "eps" and "x0"')
         if v_posterior:
             raise NotImplementedError("v_posterior != 0 changes the posterior variance buffers; not used by UPGPT")
-        # (loss_type, monitor, log_every_t, original_elbo_weight, l_simple_weight, scheduler_config, learn_logvar and
-        #  logvar_init configure the training loop of the reference and have no meaning here)
+        # loss_type, monitor, log_every_t, original_elbo_weight, l_simple_weight, scheduler_config, learn_logvar and
+        # logvar_init configure the training loop of the reference and do nothing here; the plain attributes its
+        # scripts read (main.py:653 model.monitor, classifier.py:204 diffusion_model.log_every_t) are kept
+        self.loss_type, self.monitor, self.log_every_t = loss_type, monitor, log_every_t
+        self.v_posterior, self.original_elbo_weight, self.l_simple_weight = v_posterior, original_elbo_weight, l_simple_weight
+        self.use_scheduler, self.learn_logvar = scheduler_config is not None, learn_logvar
+        if self.use_scheduler:
+            self.scheduler_config = scheduler_config
         self.parameterization, self.first_stage_key = parameterization, first_stage_key
         self.channels, self.crop_size = channels, crop_size
         self.clip_denoised, self.use_positional_encodings = clip_denoised, use_positional_encodings
@@ -193,7 +200,7 @@ class LatentDiffusion(DDPM):
         if (num_timesteps_cond or 1) > 1:
             raise NotImplementedError("num_timesteps_cond > 1 (shortened cond schedule) is not on the UPGPT path")
         self.num_timesteps_cond = 1
-        assert self.num_timesteps_cond <= kwargs["timesteps"]
+        require(self.num_timesteps_cond <= kwargs["timesteps"], "num_timesteps_cond > timesteps", ValueError)
         opts = {k: to_plain(v) for k, v in kwargs.items()}
         ckpt_path = opts.pop("ckpt_path", None)
         ignore_keys = opts.pop("ignore_keys", [])
@@ -210,6 +217,11 @@ class LatentDiffusion(DDPM):
         self.concat_mode, self.concat_key = concat_mode, concat_key
         self.scale_by_std = scale_by_std
         self.clip_denoised = False
+        self.bbox_tokenizer = None  # (ddpm.py:489; only the patch-split first stage, out of scope, would set it)
+        try:  # (ddpm.py:476-479)
+            self.num_downs = len(first_stage_config["params"]["ddconfig"]["ch_mult"]) - 1
+        except (KeyError, TypeError):
+            self.num_downs = 0
         if scale_by_std:  # (a buffer then: it is a checkpoint key)
             self.register_buffer("scale_factor", torch.tensor(scale_factor))
         if not scale_by_std:

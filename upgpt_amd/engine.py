@@ -26,6 +26,7 @@ import torch
 
 from . import _lib as L
 from .arch import UNetArch, VAEArch
+from ._check import require
 
 
 def _rup(v, m):
@@ -130,7 +131,7 @@ class Packer:
         w = w.contiguous().float()
         ln_bias = None
         if ln is not None:
-            assert w.dim() == 2 and col_map is None
+            require(w.dim() == 2 and col_map is None, "a LayerNorm can only be folded into a Linear without a column map", ValueError)
             gamma, beta = self.get(ln + ".weight").float(), self.get(ln + ".bias").float()
             ln_bias = w @ beta
             w = (w * gamma[None, :]).contiguous()
@@ -173,7 +174,7 @@ class Packer:
         low-resolution grid; tap (ty, tx) of phase (py, px) = sum of the 3x3 taps that read the same low-resolution
         pixel (summed in fp32, rounded to fp16 once)."""
         w = self.get(name + ".weight").float().to(self.dev)
-        assert w.dim() == 4 and w.shape[-1] == 3 and w.shape[-2] == 3
+        require(w.dim() == 4 and w.shape[-1] == 3 and w.shape[-2] == 3, "upsample phase weights need a 3x3 conv weight", ValueError)
         taps = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}  # (phase bit, tap) -> 3x3 taps
         parts = []
         for py in (0, 1):
@@ -185,7 +186,7 @@ class Packer:
                             for kx in taps[(px, tx)]:
                                 wp[:, :, ty, tx] += w[:, :, ky, kx]
                 packed, n_pad = self.ctx.pack_weight(wp.contiguous())
-                assert n_pad == p.n_pad
+                require(n_pad == p.n_pad, "phase weight rows differ from the 3x3 weight's", RuntimeError)
                 parts.append(packed.reshape(-1))
         p.w_phase = torch.cat(parts).contiguous()
         return p
@@ -193,7 +194,7 @@ class Packer:
     def append_1x1(self, main, skip):
         """`main` followed along K by the 1x1 weight `skip` (include/upk.h: appended K segment): one launch computes
         conv(main) + conv1x1(skip) — a ResBlock's second conv plus its skip projection (openaimodel.py:274-275)."""
-        assert skip.ksize == 1 and skip.n_pad == main.n_pad and skip.n_out == main.n_out and main.ln_colsum is None
+        require(skip.ksize == 1 and skip.n_pad == main.n_pad and skip.n_out == main.n_out and main.ln_colsum is None, "append_1x1: the appended weight must be a 1x1 with the main weight's rows", ValueError)
         p = PW()
         p.w = torch.cat([main.w.reshape(-1), skip.w.reshape(-1)])
         p.n_pad, p.n_out, p.ksize, p.k_packed, p.n_real = main.n_pad, main.n_out, main.ksize, main.k_packed, main.n_real
@@ -306,6 +307,10 @@ class Emitter:
             ent = cache.get(key)
             if ent is None and not tune_missing and key.endswith("_gs"):
                 ent = cache.get(key[:-3])  # (statistics by-product armed on a shape that was tuned without it)
+            if ent is None and not tune_missing and key.endswith("_lnr"):
+                ent = cache.get(key[:-4])  # (tuned as a plain GEMM; usable only if that choice does not split K)
+                if ent is not None and int(ent[1]) != 1 and int(ent[0]) < self.lib.upk_conv_num_configs() - self._n_as():
+                    ent = None
             if ent is None and tune_missing:
                 cfg, sk, best_us, dflt_us = self.ctx.conv_autotune(d, reps or int(os.environ.get("UPGPT_TUNE_REPS", "5")))
                 ent = cache.put(key, cfg, sk, best_us, dflt_us)
@@ -317,6 +322,15 @@ class Emitter:
             if ent is not None:
                 d.tune_cfg, d.tune_splitk = int(ent[0]) + 1, int(ent[1])
         return hits, tuned, missing
+
+    def _n_as(self):
+        """Number of A-stationary configurations (the tail of the library's configuration list: their second tuning
+        slot is output-column passes per workgroup, not a split-K factor)."""
+        n = self.lib.upk_conv_num_configs()
+        k = 0
+        while k < n and self.lib.upk_conv_config_name(n - 1 - k).decode().startswith("as"):
+            k += 1
+        return k
 
     def alloc(self, *shape, dtype=torch.float16, zero=False):
         t = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=self.dev)
@@ -409,7 +423,7 @@ class Emitter:
             out = kw.pop("out", None)
             pw = self.pk.w[name + "_ln"]
             if out is None:  # (both programs write the same buffer)
-                assert pw.n_out % 32 == 0
+                require(pw.n_out % 32 == 0, "folded-LayerNorm output width must be a multiple of 32", ValueError)
                 out = Act(self.alloc(x.M, pw.n_out), x.B, x.H, x.W, pw.n_out)
             alt = Program(self.ctx)
             self._ln_linear_plain(alt, x, name, norm, flags, out=out, **kw)
@@ -463,8 +477,8 @@ class Emitter:
             d.x2 = x2.t.data_ptr()
             d.c2 = _rup(x2.C, 32)
             d.ld2 = x2.ld
-        assert d.c1 + d.c2 == pw.k_packed, ("K mismatch", d.c1, d.c2, pw.k_packed)
-        assert d.c1 <= x1.ld and (x2 is None or d.c2 <= x2.ld)
+        require(d.c1 + d.c2 == pw.k_packed, lambda: repr(("K mismatch", d.c1, d.c2, pw.k_packed)), ValueError)
+        require(d.c1 <= x1.ld and (x2 is None or d.c2 <= x2.ld), "conv: padded channel count exceeds the row stride of its source", ValueError)
         d.batch, d.in_h, d.in_w = B, H, W
         d.ksize, d.stride = ks, stride
         d.w_packed = pw.w.data_ptr()
@@ -517,20 +531,20 @@ class Emitter:
             d.ln_rows_in = lnr.data_ptr()
             d.ln_rows_slots = 1  # (set from the producer's answer when the program runs)
         if ln_eps is not None:  # x1 is the un-normalised residual stream; pw was packed with ln=...
-            assert pw.ln_colsum is not None and x2 is None and ks == 1
+            require(pw.ln_colsum is not None and x2 is None and ks == 1, "folded LayerNorm needs a single-source 1x1 launch with an '_ln' packed weight", ValueError)
             d.ln_colsum = pw.ln_colsum.data_ptr()
             d.ln_eps = float(ln_eps)
             d.ln_dim = x1.C
         x3 = x4 = None
         if append is not None:  # appended 1x1 K segment over (x3 | x4) at the output pixel; pw from Packer.append_1x1
             x3, x4 = append
-            assert stride == 1 and not ups and (x3.B, x3.H, x3.W) == (B, Ho, Wo)
+            require(stride == 1 and not ups and (x3.B, x3.H, x3.W) == (B, Ho, Wo), "appended 1x1 segment: sources must have the output's spatial dims (stride 1, no upsample)", ValueError)
             d.x3, d.c3, d.ld3 = x3.t.data_ptr(), _rup(x3.C, 32), x3.ld
             if x4 is not None:
                 d.x4, d.c4, d.ld4 = x4.t.data_ptr(), _rup(x4.C, 32), x4.ld
-            assert d.c3 + d.c4 == pw.k_append, ("appended K mismatch", d.c3, d.c4, pw.k_append)
+            require(d.c3 + d.c4 == pw.k_append, lambda: repr(("appended K mismatch", d.c3, d.c4, pw.k_append)), ValueError)
         else:
-            assert not pw.k_append
+            require(not pw.k_append, "weight was packed with an appended segment but the launch has none", ValueError)
         use_pc = (PCONV_ON and stride == 1 and not ups and not (flags & L.F_PAD_ASYM) and ln_eps is None and vt is None
                   and (ks == 3 or gn is not None) and self.pconv_pays(M, ks, x2 is not None, append is not None))
         if use_pc:
@@ -544,6 +558,12 @@ class Emitter:
             return self.conv(P, self.groupnorm(P, x1, *gn[:5], x2=x2, sole=len(gn) > 5 and gn[5]), pw, **kw_all)
         key = self.conv_key(M, pw.n_pad, d.c1, d.c2, ks, stride, flags, residual is not None, rowvec is not None,
                             vt is not None, ln_eps is not None and lnr is None, ka=d.c3 + d.c4)
+        if lnr is not None:
+            # its own entry: the library refuses split-K for any folded LayerNorm, so a (config, split-K > 1) pair tuned
+            # for the plain GEMM of the same shape (proj_in vs attn2.q when hd == C ...) must never be pinned on it, and
+            # its sk = 1-only autotune result must not pessimise the plain GEMM either (apply_tuning falls back to the
+            # plain entry only when that one does not split K)
+            key += "_lnr"
         if use_pc:
             key += "_pc" + ("" if gn is None else "_gn%d" % int(bool(gn[3])))
         if phased:
@@ -567,12 +587,12 @@ class Emitter:
                 else:
                     alt.run(s)
 
-            P.add(run_lnr, *keep, lnr, prod, alt, cls="igemm_k%d" % ks, label=key + "_lnr")
+            P.add(run_lnr, *keep, lnr, prod, alt, cls="igemm_k%d" % ks, label=key)
         elif gn is None:
             P.add(lambda s: chk(fn(h, ref, s)), *keep, cls="igemm_k%d" % ks, label=key)
         else:
             gamma, beta, eps, silu, ws = gn[:5]
-            assert x1.C == d.c1 and (x2 is None or x2.C == d.c2), "fused GroupNorm needs channel counts that are multiples of 32"
+            require(x1.C == d.c1 and (x2 is None or x2.C == d.c2), "fused GroupNorm needs channel counts that are multiples of 32", ValueError)
             d.gni_gamma, d.gni_beta, d.gni_eps = gamma.data_ptr(), beta.data_ptr(), float(eps)
             d.gni_silu, d.gni_groups = int(bool(silu)), 32
             srcs = [x1] if x2 is None else [x1, x2]
@@ -630,7 +650,7 @@ class Emitter:
                 cap = max(32, (act.H * act.W) // 64)  # (more than 32 row blocks per sample: folded by a finalize launch)
                 sws = self.alloc(self.ctx.gn_stats_floats(act.B, d.n_pad, cap), dtype=torch.float32)
                 d.gn_stats_ws, d.gn_groups, d.gn_stats_cap = sws.data_ptr(), 32, cap
-                assert self.convs[ci][0] is d
+                require(self.convs[ci][0] is d, "conv list out of sync with GroupNorm producers", RuntimeError)
                 self.convs[ci] = (d, self.convs[ci][1] + "_gs")
                 act.gn_src = (d, ci, sws)
             armed.append((d, act.gn_src[2]))
@@ -790,7 +810,7 @@ class UNetPlan(Emitter):
 
     def __init__(self, ctx, packed: PackedUNet, B, H, W, n_ctx, rows, mode):
         super().__init__(ctx)
-        assert mode in ("forward", "sampler")
+        require(mode in ("forward", "sampler"), "UNetPlan mode must be 'forward' or 'sampler'", ValueError)
         self.pk, self.arch = packed, packed.arch
         self.B, self.H, self.W, self.n_ctx, self.rows, self.mode = B, H, W, n_ctx, rows, mode
         a = self.arch
@@ -867,7 +887,7 @@ class UNetPlan(Emitter):
                 return self.conv(P, hh, w[n + ".out_layers.3+skip"], append=(x, skip), gn=gn2, gn_stats=True)
             sk = self.conv(P, x, w[n + ".skip_connection"], x2=skip)
         else:
-            assert skip is None
+            require(skip is None, "decoder ResBlock without channel change got a skip tensor", RuntimeError)
             sk = x
         return self.conv(P, hh, w[n + ".out_layers.3"], residual=sk, gn=gn2, gn_stats=True)
 
@@ -963,14 +983,13 @@ class UNetPlan(Emitter):
 
     def load_context(self, context):
         """context: [B, n_ctx, context_dim] tensor (any float dtype / device)."""
-        assert tuple(context.shape) == (self.B, self.n_ctx, self.arch.context_dim), \
-            "context shape %s != plan %s" % (tuple(context.shape), (self.B, self.n_ctx, self.arch.context_dim))
+        require(tuple(context.shape) == (self.B, self.n_ctx, self.arch.context_dim), lambda: "context shape %s != plan %s" % (tuple(context.shape), (self.B, self.n_ctx, self.arch.context_dim)), ValueError)
         self.ctx32.copy_(context.reshape(self.B * self.n_ctx, -1).to(self.dev, torch.float32), non_blocking=True)
 
     def load_x_nchw(self, x, c_off=0, zero_pad_to=0):
         """fp32 NCHW [B, c, H, W] -> channels [c_off, c_off + c) of the stem input."""
         x = x.to(self.dev, torch.float32).contiguous()
-        assert x.shape[0] == self.B and tuple(x.shape[2:]) == (self.H, self.W)
+        require(x.shape[0] == self.B and tuple(x.shape[2:]) == (self.H, self.W), lambda: "stem input %s does not match the plan (B=%d, %dx%d)" % (tuple(x.shape), self.B, self.H, self.W), ValueError)
         self.ctx.nchw_to_nhwc(x, self.B, x.shape[1], self.H * self.W, self.xin.t, self.xin.ld, c_off, zero_pad_to, 1.0)
 
 
@@ -1062,7 +1081,7 @@ class VAEDecodePlan(Emitter):
 
     def run(self, z):
         z = z.to(self.dev, torch.float32).contiguous()
-        assert tuple(z.shape) == tuple(self.z.shape), (z.shape, self.z.shape)
+        require(tuple(z.shape) == tuple(self.z.shape), lambda: repr((z.shape, self.z.shape)), ValueError)
         self.z.copy_(z)
         self.prog.run()
         return self.img
@@ -1114,7 +1133,7 @@ class VAEEncodePlan(Emitter):
         self.pk, self.arch = packed, packed.arch
         a = self.arch
         f = a.factor
-        assert H % f == 0 and W % f == 0, "image size must be a multiple of %d" % f
+        require(H % f == 0 and W % f == 0, lambda: "image size must be a multiple of %d" % f, ValueError)
         self.x = self.alloc(B, a.in_channels, H, W, dtype=torch.float32)
         self.moments = self.alloc(B, 2 * a.embed_dim, H // f, W // f, dtype=torch.float32)
         self.gn_ws = self.alloc(max(64, ctx.groupnorm_ws_bytes(B, H * W) // 4), dtype=torch.float32)
@@ -1157,7 +1176,7 @@ class VAEEncodePlan(Emitter):
 
     def run(self, img):
         img = img.to(self.dev, torch.float32).contiguous()
-        assert tuple(img.shape) == tuple(self.x.shape), (img.shape, self.x.shape)
+        require(tuple(img.shape) == tuple(self.x.shape), lambda: repr((img.shape, self.x.shape)), ValueError)
         self.x.copy_(img)
         self.prog.run()
         return self.moments
@@ -1173,11 +1192,11 @@ class SamplerState:
         """cfg: classifier-free guidance — the plan runs 2*B rows ([unconditional ; conditional], ddim.py:173-178),
         the latent state has B = plan.B // 2 samples and the update combines the two halves of eps.
         plms: the graph is one PLMS model evaluation (upk_plms_step_f32; plan rows = evaluations = steps + 1)."""
-        assert plan.mode == "sampler"
+        require(plan.mode == "sampler", "SamplerState needs a sampler-mode plan", ValueError)
         self.plan = plan
         self.cfg = bool(cfg)
         self.plms = bool(plms)
-        assert not cfg or plan.B % 2 == 0
+        require(not cfg or plan.B % 2 == 0, "guidance runs [uncond ; cond]: the plan's batch must be even", ValueError)
         B, H, W, R = (plan.B // 2 if cfg else plan.B), plan.H, plan.W, plan.rows
         self.B = B
         self.C = channels
@@ -1190,7 +1209,11 @@ class SamplerState:
         self.hist = plan.alloc(3, B * channels * H * W, dtype=torch.float32) if plms else None
 
     def close(self):
-        """Destroys the instantiated HIP graphs (they hold device memory; called when the owning plan is dropped)."""
+        """Destroys the instantiated HIP graphs (they hold device memory; called when the owning plan is dropped).
+        sample() hands back a clone enqueued behind the last replay, so a replay may still be in flight when a new shape
+        evicts this plan: the device is drained first (HIP does not promise deferred destruction of an executing graph)."""
+        if self.graphs:
+            torch.cuda.synchronize(self.plan.dev)
         for g in self.graphs.values():
             self.plan.ctx.graph_destroy(g)
         self.graphs = {}
@@ -1214,7 +1237,7 @@ class SamplerState:
     def _emit_step(self, stream, nz, scale):
         p = self.plan
         if self.plms:
-            assert nz is None, "PLMS runs with eta = 0"
+            require(nz is None, "PLMS runs with eta = 0", ValueError)
             p.ctx._chk(p.lib.upk_plms_step_f32(p.hctx, self.x.data_ptr(), p.eps.data_ptr(), self.coefs.data_ptr(),
                                                p.step.data_ptr(), self.hist.data_ptr(), self.pred_x0.data_ptr(),
                                                p.xin.t.data_ptr(), p.xin.ld, self.B, self.C, p.H * p.W, float(scale),
@@ -1255,6 +1278,7 @@ class SamplerState:
             p.ctx._chk(rc)
             torch.cuda.current_stream(p.dev).wait_stream(side)
             if len(self.graphs) >= 8:  # guidance scales seen so far: bound the number of instantiated graphs
+                torch.cuda.synchronize(p.dev)  # (the evicted graph may still be executing)
                 p.ctx.graph_destroy(self.graphs.pop(next(iter(self.graphs))))
             g = self.graphs[key] = gh
         return g

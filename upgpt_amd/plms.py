@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from .ddim import DDIMSampler
+from ._check import require
 
 # Adams-Bashforth weights on [e_t, e_{t-1}, e_{t-2}, e_{t-3}] by available history (plms.py:224-234)
 _AB = {1: (3 / 2, -1 / 2), 2: (23 / 12, -16 / 12, 5 / 12), 3: (55 / 24, -59 / 24, 37 / 24, -9 / 24)}
@@ -69,7 +70,7 @@ class PLMSSampler(DDIMSampler):
             ts_next = torch.full((b,), int(time_range[min(i + 1, len(time_range) - 1)]), device=device,
                                  dtype=torch.long)
             if mask is not None:
-                assert x0 is not None
+                require(x0 is not None, "mask given without x0", ValueError)
                 img = self.model.q_sample(x0, ts) * mask + (1. - mask) * img
             img, pred_x0, e_t = self.p_sample_plms(img, cond, ts, index=index, temperature=temperature,
                                                    noise_dropout=noise_dropout, score_corrector=score_corrector,
@@ -111,12 +112,12 @@ class PLMSSampler(DDIMSampler):
             plan.load_x_nchw(torch.cat([st.x, st.x]) if cfg else st.x, 0, 0)
             if c_concat is not None:
                 plan.load_x_nchw(c_concat, C, plan.cin_pad)
-            assert C + (0 if c_concat is None else c_concat.shape[1]) == unet.in_channels
+            require(C + (0 if c_concat is None else c_concat.shape[1]) == unet.in_channels, "latent + concat channels != UNet in_channels", ValueError)
             order = np.arange(S)[::-1].copy()
             t_desc = np.asarray(timesteps)[order].astype(np.float32)
             # evaluation k runs at: t_0, then (x~, t_next = t_1) for the Euler corrector, then t_1, t_2, ...
             t_eval = np.concatenate([t_desc[:1], t_desc[min(1, S - 1):min(1, S - 1) + 1], t_desc[1:]])
-            assert t_eval.shape[0] == S + 1
+            require(t_eval.shape[0] == S + 1, "PLMS evaluates S + 1 times", RuntimeError)
             plan.t_rows.copy_(torch.as_tensor(t_eval))
             plan.load_context(c_cross)
             st.coefs[:S].copy_(ddim_coefficient_table(self.ddim_alphas, self.ddim_alphas_prev, self.ddim_sigmas,
@@ -154,7 +155,7 @@ class PLMSSampler(DDIMSampler):
                                                 self._cat_cond(unconditional_conditioning, c)).chunk(2)
                 e = e_u + unconditional_guidance_scale * (e - e_u)
             if score_corrector is not None:
-                assert self.model.parameterization == "eps"
+                require(self.model.parameterization == "eps", "classifier-free guidance / score correction needs an eps-parameterised model", NotImplementedError)
                 e = score_corrector.modify_score(self.model, e, xx, tt, c, **corrector_kwargs)
             return e
 

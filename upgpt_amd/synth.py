@@ -14,6 +14,7 @@ import zlib
 
 import numpy as np
 import torch
+from ._check import require
 
 RECIPE_VERSION = 1
 
@@ -56,7 +57,7 @@ def fill_module_(module, prefixes=("model.diffusion_model.", "first_stage_model.
                 if s_name in sd:
                     new[s_name] = v.clone()
     missing, unexpected = module.load_state_dict(new, strict=False)
-    assert not unexpected, unexpected
+    require(not unexpected, lambda: "unexpected keys: %s" % (unexpected,), RuntimeError)
     return new
 
 

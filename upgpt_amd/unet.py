@@ -9,6 +9,7 @@ import torch
 
 from .arch import UNetArch
 from .params import ParamTree, weights_fingerprint
+from ._check import require
 
 
 class UNetModel(ParamTree):
@@ -99,13 +100,13 @@ class UNetModel(ParamTree):
     @torch.no_grad()
     def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
         """x [N, in_channels, H, W], timesteps [N], context [N, n_ctx, context_dim] -> eps [N, out, H, W]."""
-        assert y is None, "must specify y if and only if the model is class-conditional"
+        require(y is None, "must specify y if and only if the model is class-conditional", NotImplementedError)
         if context is None:
             raise NotImplementedError("UNetModel without context (cross-attn defaults to self-attn) is not on the "
                                       "UPGPT path")
         B, Cin, H, W = x.shape
-        assert Cin == self.in_channels, "expected %d input channels, got %d" % (self.in_channels, Cin)
-        assert timesteps is not None and timesteps.shape[0] == B
+        require(Cin == self.in_channels, lambda: "expected %d input channels, got %d" % (self.in_channels, Cin), ValueError)
+        require(timesteps is not None and timesteps.shape[0] == B, "timesteps must be given, one per sample", ValueError)
         pl = self.plan(B, H, W, context.shape[1], B, "forward")
         with torch.cuda.device(pl.dev):
             pl.load_x_nchw(x, 0, pl.cin_pad)

@@ -9,6 +9,7 @@ import torch
 from .arch import VAEArch
 from .config import instantiate_from_config
 from .params import ParamTree, weights_fingerprint
+from ._check import require
 
 
 class DiagonalGaussianDistribution(object):
@@ -47,7 +48,7 @@ class AutoencoderKL(ParamTree):
     def __init__(self, ddconfig, lossconfig=None, embed_dim=None, ckpt_path=None, ignore_keys=[], image_key="image",
                  colorize_nlabels=None, monitor=None):
         super().__init__()
-        assert ddconfig["double_z"]
+        require(ddconfig["double_z"], "AutoencoderKL needs ddconfig.double_z", NotImplementedError)
         self.image_key = image_key
         self.arch = VAEArch(ddconfig, embed_dim)
         self.embed_dim = embed_dim
@@ -57,7 +58,7 @@ class AutoencoderKL(ParamTree):
         except Exception:
             self.loss = None
         if colorize_nlabels is not None:
-            assert type(colorize_nlabels) == int
+            require(type(colorize_nlabels) == int, "colorize_nlabels must be an int", TypeError)
             self.register_buffer("colorize", torch.randn(3, colorize_nlabels, 1, 1))
         if monitor is not None:
             self.monitor = monitor
