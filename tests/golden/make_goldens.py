@@ -2,7 +2,7 @@
 """Generates the golden fixtures under tests/golden/ by running the REAL reference
 (/root/reference, pure Python, imported read-only) on CPU in the build container.
 
-    python tests/golden/make_goldens.py [--only tiny|bbox|upscale|schedule|encode|plms|extra]
+    python tests/golden/make_goldens.py [--only tiny|bbox|upscale|schedule|encode|plms|extra|a15|upscale64]
 
 The reference never travels: only its OUTPUTS (small arrays) and state-dict key/shape
 manifests are committed.  Weights and inputs are regenerated from upgpt_amd/synth.py's
@@ -340,6 +340,96 @@ def gen_extra(out):
     print("extra ->", out, sorted(g))
 
 
+class RandnFeed:
+    """Context manager: torch.randn((1, C, H, W), device=...) — the seeded x_T of log_images (ddpm.py:1422-1426), drawn
+    from the CPU generator here and from the CUDA generator on the device — returns the recipe tensor instead, on both
+    sides (tests/test_model_gpu.py patches it the same way); every other call goes to the real torch.randn."""
+
+    def __init__(self, x_T):
+        self.x_T, self.hits = x_T, 0
+
+    def __enter__(self):
+        self.orig = torch.randn
+        feed = self
+
+        def randn(*size, **kw):
+            shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else tuple(size)
+            if shape == tuple(feed.x_T.shape) and kw.get("generator") is None:
+                feed.hits += 1
+                return feed.x_T.clone().to(kw.get("device") or "cpu")
+            return feed.orig(*size, **kw)
+
+        torch.randn = randn
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn = self.orig
+
+
+def a15_batch(B=2):
+    """The DeepFashion-shaped batch LatentDiffusion.get_input / log_images read (deepfashion_inshop.py keys)."""
+    g0 = torch.Generator().manual_seed(3)
+    return {"image": torch.rand(B, 256, 192, 3, generator=g0) * 2 - 1,
+            "txt": torch.randn(B, 77, 768, generator=g0), "styles": 0.45 * torch.randn(B, 9, 768, generator=g0),
+            "smpl": 0.5 * torch.randn(B, 1, 85, generator=g0), "person_mask": synth.person_mask(B, 32, 24)}
+
+
+def gen_a15(out):
+    """the reference's own LatentDiffusion.get_input (ddpm.py:684-769) and
+    log_images (ddpm.py:1380-1499) on the tiny model — conditioning assembly text | styles | smpl, c_concat, the seeded
+    x_T repeated over the batch, the EMA scope (shadow weights != live weights here, so skipping it shows), DDIM, decode."""
+    model, params = build_reference("tiny")
+    synth.fill_ema_(model, salt=1)  # EMA shadow = a DIFFERENT recipe draw than the live weights
+    B = 2
+    batch = a15_batch(B)
+    g = {}
+    torch.manual_seed(1234)
+    z, c, x, xrec, xc = model.get_input(batch, "image", return_first_stage_outputs=True, force_c_encode=True,
+                                        return_original_cond=True, bs=B)
+    g["c_crossattn"] = c["c_crossattn"].numpy()
+    g["c_concat"] = c["c_concat"][0].numpy()
+    g["x"] = pool8(x)
+    # the posterior MODE (get_input samples the posterior with the device RNG: not comparable across devices)
+    g["z_mode_scaled"] = model.get_first_stage_encoding(model.encode_first_stage(x).mode()).numpy()
+    x_T = synth.synth_inputs(1, (32, 24), 4, 87, 768, seed=11)["x_T"]
+    ref_ddim.noise_like = NoiseFeed(None)
+    with RandnFeed(x_T) as feed:
+        log = model.log_images(batch, N=B, ddim_steps=5, ddim_eta=0.0, seed=11)
+    assert feed.hits == 1, feed.hits
+    g["samples_pool8"] = pool8(log["samples"])
+    g["samples_stats"] = stats(log["samples"])
+    g["samples_corner"] = log["samples"][:, :, :8, :8].numpy()
+    # the latent behind it (same call sequence as log_images: ema_scope -> sample_log), and WITHOUT the EMA scope
+    ref_ddim.noise_like = NoiseFeed(None)
+    with model.ema_scope():
+        zs, _ = model.sample_log(cond=c, batch_size=B, ddim=True, ddim_steps=5, eta=0.0, x_T=x_T.repeat(B, 1, 1, 1))
+    g["samples_z"] = zs.numpy()
+    ref_ddim.noise_like = NoiseFeed(None)
+    zl, _ = model.sample_log(cond=c, batch_size=B, ddim=True, ddim_steps=5, eta=0.0, x_T=x_T.repeat(B, 1, 1, 1))
+    g["samples_z_live_weights"] = zl.numpy()
+    assert float((zs - zl).abs().max()) > 1e-3  # (the EMA scope matters in this fixture)
+    g["x_T_crc"] = np.asarray(synth.crc_of(x_T), dtype=np.uint64)
+    np.savez_compressed(out, **g)
+    print("a15 ->", out, {k: v.shape for k, v in g.items()})
+
+
+def gen_upscale64(out):
+    """BASELINE.json configs[4] as worded — upscale model, 64x64 latent, 50-step DDIM: B = 1 reference run (the GPU test
+    runs it at B = 1 and as sample 0 of the B = 4 batch)."""
+    model, params = build_reference("upscale")
+    inp = synth.synth_inputs(1, (64, 64), 3, 86, 768, seed=31, concat_channels=3)
+    cond = {"c_crossattn": inp["c_crossattn"], "c_concat": [inp["c_concat"]]}
+    g = {"unet_eps": model.apply_model(inp["x_T"], torch.tensor([981]), cond).numpy()}
+    ref_ddim.noise_like = NoiseFeed(None)
+    z, _ = ref_ddim.DDIMSampler(model).sample(S=50, batch_size=1, shape=(3, 64, 64), conditioning=cond, eta=0.0,
+                                              x_T=inp["x_T"].clone(), verbose=False)
+    g["ddim_S50/z"] = z.numpy()
+    g["crc_inputs"] = np.asarray([synth.crc_of(inp["x_T"]), synth.crc_of(inp["c_crossattn"]), synth.crc_of(inp["c_concat"])],
+                                 dtype=np.uint64)
+    np.savez_compressed(out, **g)
+    print("upscale64 ->", out, z.shape)
+
+
 def gen_schedule(out):
     g = {}
     for name, (ls, le) in {"bbox": (0.00085, 0.012), "upscale": (0.0001, 0.02)}.items():
@@ -370,9 +460,13 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    kinds = [a.only] if a.only else ["schedule", "tiny", "bbox", "upscale", "encode", "plms", "extra"]
+    kinds = [a.only] if a.only else ["schedule", "tiny", "bbox", "upscale", "encode", "plms", "extra", "a15", "upscale64"]
     for k in kinds:
-        if k == "extra":
+        if k == "a15":
+            gen_a15(os.path.join(HERE, "a15.npz"))
+        elif k == "upscale64":
+            gen_upscale64(os.path.join(HERE, "upscale64.npz"))
+        elif k == "extra":
             gen_extra(os.path.join(HERE, "extra.npz"))
         elif k == "plms":
             for kind in ("tiny", "bbox"):

@@ -7,13 +7,12 @@ from .config import instantiate_from_config, load_config  # noqa: F401
 __version__ = "0.1.0"
 
 
-def build_model(kind="bbox", overrides=None):
-    """LatentDiffusion from the restated reference configs in synth.py (`bbox`, `upscale`,
-    `tiny`), conditioning stages replaced by DummyModel (embeddings fed directly)."""
+def model_params(kind="bbox", overrides=None):
+    """Constructor kwargs of LatentDiffusion for the restated reference configs in synth.py (`bbox`, `upscale`, `tiny`),
+    conditioning stages replaced by DummyModel (embeddings fed directly)."""
     import copy
 
     from . import synth
-    from .ddpm import LatentDiffusion
     unet = {"bbox": synth.BBOX_UNET, "tiny": synth.TINY_UNET, "upscale": synth.UPSCALE_UNET}[kind]
     dd = {"bbox": synth.BBOX_DDCONFIG, "tiny": synth.TINY_DDCONFIG, "upscale": synth.UPSCALE_DDCONFIG}[kind]
     up = kind == "upscale"
@@ -36,4 +35,16 @@ def build_model(kind="bbox", overrides=None):
     )
     if overrides:
         p.update(overrides)
-    return LatentDiffusion(**p).eval()
+    return p
+
+
+def model_config(kind="bbox", overrides=None):
+    """The same as a config tree shaped like configs/deepfashion/bbox.yaml ({'model': {'target', 'params'}}), with the
+    reference's dotted path as target: what load_model_from_config / instantiate_from_config take."""
+    return {"model": {"target": "ldm.models.diffusion.ddpm.LatentDiffusion", "params": model_params(kind, overrides)}}
+
+
+def build_model(kind="bbox", overrides=None):
+    """LatentDiffusion(**model_params(kind, overrides)).eval()"""
+    from .ddpm import LatentDiffusion
+    return LatentDiffusion(**model_params(kind, overrides)).eval()

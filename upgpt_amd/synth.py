@@ -14,7 +14,6 @@ import zlib
 
 import numpy as np
 import torch
-from ._check import require
 
 RECIPE_VERSION = 1
 
@@ -57,7 +56,22 @@ def fill_module_(module, prefixes=("model.diffusion_model.", "first_stage_model.
                 if s_name in sd:
                     new[s_name] = v.clone()
     missing, unexpected = module.load_state_dict(new, strict=False)
-    require(not unexpected, lambda: "unexpected keys: %s" % (unexpected,), RuntimeError)
+    if unexpected:  # (plain raise: this module is also loaded stand-alone by tests/golden/make_goldens.py)
+        raise RuntimeError("unexpected keys: %s" % (unexpected,))
+    return new
+
+
+def fill_ema_(module, salt=1):
+    """Gives the LitEma shadow buffers their OWN recipe draw (salt != 0: different from the live weights), so that a test
+    can tell whether ema_scope() was honoured.  Key = the live parameter's name, as in fill_module_."""
+    sd = module.state_dict()
+    new = {}
+    for k, v in sd.items():
+        if k.startswith("model.diffusion_model."):
+            s_name = "model_ema." + k[len("model."):].replace(".", "")
+            if s_name in sd:
+                new[s_name] = synth_tensor(k, tuple(v.shape), salt)
+    module.load_state_dict(new, strict=False)
     return new
 
 
