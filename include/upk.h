@@ -248,6 +248,39 @@ const char* upk_pconv_config_name(int cfg);
  * its domain (the launch then falls back to the implicit-GEMM kernels and REFUSES gni_mode != 0). */
 int upk_pconv_supported(upk_ctx* ctx, const upk_conv_desc* d);
 
+/* Fused feed-forward tail of a SpatialTransformer block — BasicTransformerBlock.norm3 -> FeedForward (GEGLU, erf GELU)
+ * -> + residual (attention.py:42-64, 215) followed by SpatialTransformer.proj_out -> + x_in (attention.py:259-261) —
+ * as ONE launch; the 4c-wide hidden activation stays in LDS:
+ *     h   = (xn W1v^T + b1v) * gelu(xn W1g^T + b1g),  xn = LayerNorm(x)          [m, inner]
+ *     y   = residual + [h | x] W2^T + b2                                          [m, n_out]
+ * x: un-normalised rows [m, ldx] (c channels, c % 224 == 0); w1 / b1 / u1: the GEGLU Linear packed as for
+ * upk_conv2d_nhwc_f16 with UPK_F_GEGLU and ln_colsum (W * gamma in [32 value | 32 gate] row blocks, b + W beta, column
+ * sums of the fp16-rounded rows), inner = 4 c; w2: packed [n_pad rows][K = inner + c] weight whose K order is [h | x]
+ * (Packer.append_1x1(P F2, P) for ff.net.2 / proj_out), b2 [n_pad]; n_pad <= 256.  rows_per_wg: 32 or 64 (0 = 64).
+ * gn_stats_ws != NULL: per-(row block, channel) GroupNorm partials [m / hw][hw / rows_per_wg][2][n_pad] of y, as
+ * upk_conv_desc.gn_stats_ws mode 2 (hw = rows per sample, a multiple of rows_per_wg). */
+typedef struct upk_mlp_desc {
+  const void* x;
+  int32_t ldx, m, c, inner;
+  const void* w1;
+  const float* b1;
+  const float* u1;
+  float ln_eps;
+  int32_t ln_dim;
+  const void* w2;
+  const float* b2;
+  int32_t n_out, n_pad;
+  const void* residual;
+  int32_t ld_res;
+  void* y;
+  int32_t ldy;
+  float* gn_stats_ws;
+  int32_t hw, rows_per_wg;
+} upk_mlp_desc;
+int upk_geglu_mlp_f16(upk_ctx* ctx, const upk_mlp_desc* d, upk_stream stream);
+/* 1 if upk_geglu_mlp_f16 takes the shape (channel family, LDS budget, row-block geometry), else 0. */
+int upk_geglu_mlp_supported(upk_ctx* ctx, const upk_mlp_desc* d);
+
 /* Convenience wrapper: y[M,N] = act(A[M,K] @ W^T + bias) + residual. */
 int upk_gemm_f16(upk_ctx* ctx, const void* a, int lda, int m, int k, const void* w_packed,
                  int n_out, int n_pad, const float* bias, const void* residual, int ld_res,

@@ -20,6 +20,7 @@ SYMBOLS = [
     "upk_pack_weight_f16", "upk_packed_weight_bytes", "upk_conv2d_nhwc_f16", "upk_gemm_f16",
     "upk_conv_autotune", "upk_conv_override", "upk_conv_num_configs", "upk_conv_config_name", "upk_conv_gn_fused",
     "upk_pconv_num_configs", "upk_pconv_config_name", "upk_pconv_supported", "upk_conv_ln_rows",
+    "upk_geglu_mlp_f16", "upk_geglu_mlp_supported",
     "upk_attention_f16", "upk_groupnorm_nhwc_f16", "upk_groupnorm_stats_nhwc_f16", "upk_groupnorm_chunks", "upk_groupnorm_apply_nhwc_f16", "upk_groupnorm_finalize_f32", "upk_groupnorm_ws_bytes",
     "upk_layernorm_f16", "upk_timestep_embed_f16",
     "upk_nchw_f32_to_nhwc_f16", "upk_nhwc_f16_to_nchw_f32", "upk_f32_to_f16", "upk_ddim_step_f32",
@@ -72,6 +73,17 @@ class ConvDesc(C.Structure):
     ]
 
 
+class MlpDesc(C.Structure):
+    """Mirror of struct upk_mlp_desc (include/upk.h)."""
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int32), ("m", C.c_int32), ("c", C.c_int32), ("inner", C.c_int32),
+        ("w1", C.c_void_p), ("b1", C.c_void_p), ("u1", C.c_void_p), ("ln_eps", C.c_float), ("ln_dim", C.c_int32),
+        ("w2", C.c_void_p), ("b2", C.c_void_p), ("n_out", C.c_int32), ("n_pad", C.c_int32),
+        ("residual", C.c_void_p), ("ld_res", C.c_int32), ("y", C.c_void_p), ("ldy", C.c_int32),
+        ("gn_stats_ws", C.c_void_p), ("hw", C.c_int32), ("rows_per_wg", C.c_int32),
+    ]
+
+
 _lib = None
 _lib_lock = threading.Lock()
 
@@ -109,6 +121,8 @@ def load_library(path=None):
             "upk_pconv_config_name": (C.c_char_p, [i32]),
             "upk_pconv_supported": (C.c_int, [vp, C.POINTER(ConvDesc)]),
             "upk_conv_ln_rows": (C.c_int, [vp, C.POINTER(ConvDesc), C.POINTER(C.c_int)]),
+            "upk_geglu_mlp_f16": (C.c_int, [vp, C.POINTER(MlpDesc), vp]),
+            "upk_geglu_mlp_supported": (C.c_int, [vp, C.POINTER(MlpDesc)]),
             "upk_attention_f16": (C.c_int, [vp, vp, i32, i64, vp, i32, i64, vp, i32, vp, i32, i64,
                                             i32, i32, i32, i32, i32, f32, vp]),
             "upk_attention_causal_f16": (C.c_int, [vp, vp, i32, i64, vp, i32, i64, vp, i32, vp, i32, i64,

@@ -48,9 +48,9 @@ struct AsArgs {
   int e1, e2, e3;  // channel offsets where the 2nd / 3rd / 4th source start (multiples of 32)
   int ld1, ld2, ld3, ld4;
   int M, npad, n_out, nch, flags, ldr, ldy;
-  int ppw, npass, skew;
+  int ppw, npass;
   int tiles_m, tiles_n, xm_pm, xm_pn, xm_mi, xm_nj;
-  int lnr_slots, rot;
+  int lnr_slots;
   float ln_inv_dim, ln_eps;
 };
 #define AS_PIN(v) asm volatile("" ::"s"(v))
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(const AsArgs s, const Ige
   AS_PIN(s.M); AS_PIN(s.npad); AS_PIN(s.nch); AS_PIN(s.flags); AS_PIN(s.ppw); AS_PIN(s.npass);
   AS_PIN(s.tiles_m); AS_PIN(s.tiles_n); AS_PIN(s.xm_pm); AS_PIN(s.xm_pn); AS_PIN(s.xm_mi); AS_PIN(s.xm_nj);
   AS_PIN(s.bias); AS_PIN(s.res); AS_PIN(s.y); AS_PIN(s.ln_u); AS_PIN(s.lnr_in); AS_PIN(s.n_out); AS_PIN(s.ldr);
-  AS_PIN(s.ldy); AS_PIN(s.skew); AS_PIN(s.lnr_slots);
+  AS_PIN(s.ldy); AS_PIN(s.lnr_slots);
 #undef ABL_ON
 #if defined(UPK_DEV)  // (phase ablation hooks: dev builds only — as runtime tests they cost branches in every K step)
 #define ABL_ON(f) ((s.flags & (f)) != 0)
@@ -262,11 +262,6 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(const AsArgs s, const Ige
   // which epilogue (workgroup-uniform): the two straight-line ones with their operands requested at the START of the
   // pass (a dependent load round trip behind the K loop costs ~1 us per pass), or igemm_common.h's general one
   STAMP(4);
-  // the second wave of every SIMD starts half a K phase late, so that one wave's epilogue (VALU) runs under its
-  // partner's K loop (matrix pipe) instead of both queueing for the same pipe in lockstep
-  if (wave >= 4)
-    for (int i = 0; i < s.skew; ++i) __builtin_amdgcn_s_sleep(8);
-
   // ---- 4. passes: K loop out of the resident tile + the register ring, then the epilogue of the pass
   const unsigned la = (unsigned)(lc * 32 + lds_swz(lc, lg) * 8) * 2u;  // this lane's byte offset inside a 16-row group
   const char* sm = (const char*)smem;
@@ -367,7 +362,7 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(const AsArgs s, const Ige
             const f32x4 v = acc[i][jv] + bv[jv], g = acc[i][jg] + bv[jg];
             f16x4 o;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = (f16)(v[k] * upk_gelu(g[k]));
+            for (int k = 0; k < 4; ++k) o[k] = (f16)upk_geglu_mul(v[k], g[k]);
             if (m < s.M && n < s.npad && oc < s.n_out) *(f16x4*)(yrow + oc) = o;
           }
         }
@@ -489,11 +484,6 @@ int astat_launch(upk_ctx* ctx, IgemmArgs& a, int c, const AsPlan& pl, dim3 grid,
   s.ppw = pl.ppw, s.npass = pl.npass;
   s.tiles_m = a.tiles_m, s.tiles_n = a.tiles_n, s.xm_pm = a.xm_pm, s.xm_pn = a.xm_pn, s.xm_mi = a.xm_mi, s.xm_nj = a.xm_nj;
   s.lnr_slots = a.lnr_slots, s.ln_inv_dim = a.ln_inv_dim, s.ln_eps = a.ln_eps;
-  static const int rot_env = getenv("UPK_AS_ROT") ? atoi(getenv("UPK_AS_ROT")) : 1;
-  s.rot = rot_env;
-  // half a (shared) K phase, in units of s_sleep 8 (512 cycles): nch chunks x MI x NI MFMAs of 16 cycles, two waves
-  static const int skew_env = getenv("UPK_AS_SKEW") ? atoi(getenv("UPK_AS_SKEW")) : -1;
-  s.skew = skew_env >= 0 ? skew_env : (pl.ppw > 1 ? (a.nchunks * k.mi * k.ni * 16 + 256) / 512 : 0);
   hipLaunchKernelGGL(fast ? k.fn : k.fn_gen, grid, dim3(512), (size_t)pl.lds_bytes, stream, s, a);
   return upk_check_launch(ctx, "igemm_as");
 }

@@ -268,7 +268,7 @@ struct Epi {
       // packed rows: [32 value | 32 gate] per 64-row block
       g += bg;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = v[k] * upk_gelu(g[k]);
+      for (int k = 0; k < 4; ++k) v[k] = upk_geglu_mul(v[k], g[k]);
     }
     const int oc = out_col(a, n);  // output column
     const bool to_vt = a.vt && n >= a.vt_from;
@@ -564,7 +564,7 @@ struct Epi {
         const f32x4 g = acc[i][j + 2 < NI ? j + 2 : j] + bv[j + 2 < NI ? j + 2 : j];
         f16x4 o;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = (f16)(v[k] * upk_gelu(g[k]));
+        for (int k = 0; k < 4; ++k) o[k] = (f16)upk_geglu_mul(v[k], g[k]);
         if (ok && n < a.npad && oc < a.n_out) *(f16x4*)(yrow + oc) = o;
       }
     }

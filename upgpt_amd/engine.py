@@ -76,6 +76,10 @@ UPS_PHASES = os.environ.get("UPGPT_UPS_PHASES", "1") == "1"
 LN_ROWS = os.environ.get("UPGPT_LN_ROWS", "1") == "1"
 QPROJ_FUSE = os.environ.get("UPGPT_QPROJ_FUSE", "1") == "1"
 GN_REDUCE_APPLY = os.environ.get("UPGPT_GN_REDUCE_APPLY", "1") == "1"
+# fused feed-forward tail (csrc/mlp.hip: GEGLU -> ff.net.2 o proj_out with the hidden activation in LDS): "auto" = where
+# M / rows-per-workgroup covers the chip (the 32x32 level at B = 8), "0" off, "1" wherever the kernel takes the shape
+MLP_FUSE = os.environ.get("UPGPT_MLP_FUSE", "auto")
+MLP_ROWS = int(os.environ.get("UPGPT_MLP_ROWS", "0"))  # rows per workgroup (32 / 64; 0 = by M)
 PCONV_ON = PCONV_MODE != "0"
 LN_LAUNCH_US = 3.0  # what a separate LayerNorm launch costs inside the replayed forward (class ablation: 3.8)
 
@@ -606,6 +610,9 @@ class Emitter:
             def run(s):
                 info = []
                 for dsrc, sws in (armed or ()):
+                    if isinstance(dsrc, Emitter.GnProvider):
+                        info.append((2, dsrc.nblk, dsrc.ld, sws.data_ptr()))
+                        continue
                     mode, nblk = C.c_int(0), C.c_int(0)
                     chk(fused_fn(h, C.byref(dsrc), C.byref(mode), C.byref(nblk)))
                     info.append((mode.value, nblk.value, dsrc.n_pad, sws.data_ptr()))
@@ -625,6 +632,12 @@ class Emitter:
         P.igemm_flops += 2 * M * pw.n_real * pw.k_real
         return ret
 
+    class GnProvider:
+        """A launch other than upk_conv2d_nhwc_f16 that leaves the per-(row block, channel) GroupNorm partials of its
+        output (mode 2 of include/upk.h gn_stats_ws): (stats buffer, nblk, ld) are fixed when it is emitted."""
+        def __init__(self, sws, nblk, ld):
+            self.sws, self.nblk, self.ld = sws, nblk, ld
+
     def _arm_gn_sources(self, acts):
         """Arms the producer launch of every source Act to leave the GroupNorm partial sums of its output
         (include/upk.h gn_stats_ws).  Returns [(producer ConvDesc, stats buffer)] or None when a source has no such
@@ -636,14 +649,17 @@ class Emitter:
             if os.environ.get("UPGPT_GN_2SRC", "1") != "1":
                 return None
             for sr in srcs:
-                if sr[0].pc_enable:
-                    continue  # the patch kernel never splits K
+                if isinstance(sr, Emitter.GnProvider) or sr[0].pc_enable:
+                    continue  # (never split K)
                 key = self.convs[sr[1]][1]
                 e = TUNE_CACHE.get(key) or TUNE_CACHE.get(key[:-3] if key.endswith("_gs") else key + "_gs")
                 if e is None or e[1] != 1:
                     return None
         armed = []
         for act in acts:
+            if isinstance(act.gn_src, Emitter.GnProvider):
+                armed.append((act.gn_src, act.gn_src.sws))
+                continue
             d = act.gn_src[0]
             if not d.gn_stats_ws:  # arm the producer and rename its tuning key
                 ci = act.gn_src[1]
@@ -676,7 +692,7 @@ class Emitter:
             fused_fn, apply_fn = self.lib.upk_conv_gn_fused, self.lib.upk_groupnorm_apply_nhwc_f16
             fin_fn = self.lib.upk_groupnorm_finalize_f32
             mine = None
-            if GN_REDUCE_APPLY and x2 is None and not armed[0][0].gno_y:
+            if GN_REDUCE_APPLY and x2 is None and not isinstance(armed[0][0], Emitter.GnProvider) and not armed[0][0].gno_y:
                 # a producer that splits K normalises in its reduce pass (include/upk.h gno_*): this op then launches nothing
                 mine = armed[0][0]
                 mine.gno_gamma, mine.gno_beta, mine.gno_eps = gamma.data_ptr(), beta.data_ptr(), float(eps)
@@ -685,6 +701,9 @@ class Emitter:
             def run(s):
                 info = []
                 for d, sws in armed:
+                    if isinstance(d, Emitter.GnProvider):
+                        info.append((2, d.nblk, d.ld, sws.data_ptr()))
+                        continue
                     mode, nblk = C.c_int(0), C.c_int(0)
                     chk(fused_fn(h, C.byref(d), C.byref(mode), C.byref(nblk)))
                     info.append((mode.value if mode.value != 3 or d is mine else 0, nblk.value, d.n_pad, sws.data_ptr()))
@@ -716,6 +735,45 @@ class Emitter:
         a = (x.t.data_ptr(), x.ld, x.M, x.C, gamma.data_ptr(), beta.data_ptr(), float(eps), y.t.data_ptr(), y.ld)
         P.add(lambda s: chk(fn(h, *a, s)), x, gamma, beta, y, cls="layernorm", label="ln M%d C%d" % (x.M, x.C))
         return y
+
+    def mlp_rows(self, M):
+        """Rows per workgroup of the fused feed-forward kernel: 64 while that still gives every CU a workgroup."""
+        if MLP_ROWS in (32, 64):
+            return MLP_ROWS
+        return 64 if M // 64 >= self.ctx.num_cus else 32
+
+    def geglu_mlp(self, P, t2, x_in, pw1, pw2, gn_stats=True):
+        """norm3 -> GEGLU -> ff.net.2 (+ t2) -> proj_out (+ x_in) as ONE launch (include/upk.h upk_geglu_mlp_f16), or None
+        when the shape is outside the kernel's domain / the chip would not be covered (UPGPT_MLP_FUSE).
+        pw1: the "_ln" GEGLU packing, pw2: Packer.append_1x1(P F2, P) — K order [h | t2]."""
+        if MLP_FUSE == "0" or t2.C != t2.ld:
+            return None
+        M, C_ = t2.M, t2.C
+        rows = self.mlp_rows(M)
+        d = L.MlpDesc()
+        d.x, d.ldx, d.m, d.c, d.inner = t2.t.data_ptr(), t2.ld, M, C_, pw1.n_out
+        d.w1, d.b1, d.u1 = pw1.w.data_ptr(), pw1.bias.data_ptr(), pw1.ln_colsum.data_ptr()
+        d.ln_eps, d.ln_dim = 1e-5, C_
+        d.w2, d.b2, d.n_out, d.n_pad = pw2.w.data_ptr(), pw2.bias.data_ptr(), pw2.n_out, pw2.n_pad
+        d.residual, d.ld_res = x_in.t.data_ptr(), x_in.ld
+        hw = t2.H * t2.W
+        d.hw, d.rows_per_wg = hw, rows
+        if not self.lib.upk_geglu_mlp_supported(self.hctx, C.byref(d)):
+            return None
+        if MLP_FUSE == "auto" and (M + rows - 1) // rows < (self.ctx.num_cus * 3) // 4:
+            return None  # (every workgroup streams both weights in full: it pays only when M / rows covers the chip)
+        out = Act(self.alloc(M, pw2.n_out), t2.B, t2.H, t2.W, pw2.n_out)
+        d.y, d.ldy = out.t.data_ptr(), out.ld
+        sws = None
+        if gn_stats and hw % rows == 0 and hw // rows <= 32:
+            sws = self.alloc(self.ctx.gn_stats_floats(t2.B, pw2.n_pad), dtype=torch.float32)
+            d.gn_stats_ws = sws.data_ptr()
+            out.gn_src = Emitter.GnProvider(sws, hw // rows, pw2.n_pad)
+        fn, h, chk = self.lib.upk_geglu_mlp_f16, self.hctx, self._chk
+        P.add(lambda s: chk(fn(h, C.byref(d), s)), d, t2, x_in, pw1, pw2, out, sws, cls="igemm_k1",
+              label="mlp M%d C%d rows%d" % (M, C_, rows))
+        P.igemm_flops += 2 * M * (2 * pw1.n_out * C_ + pw2.n_real * (pw1.n_out + C_))
+        return out
 
     def attention(self, P, q, ldq, qbs, k, ldk, kbs, vt, vt_ld, out, ldo, obs, B, heads, nq, nkv, dp, scale):
         fn, h, chk = self.lib.upk_attention_f16, self.hctx, self._chk
@@ -935,6 +993,9 @@ class UNetPlan(Emitter):
         P.attn_flops += 4 * B * heads * HW * self.n_ctx * dh
         t2 = self.conv(P, a2, w[t + ".attn2.to_out"], residual=t1)
         # GEGLU feed-forward
+        fused = self.geglu_mlp(P, t2, x, w[t + ".ff.geglu_ln"], w[n + ".ff.out+proj_out"])
+        if fused is not None:
+            return fused
         ff = self.ln_linear(P, t2, t + ".ff.geglu", t + ".norm3", flags=L.F_GEGLU)
         if self.fold_ff_out(ff, t2, w[t + ".ff.out"]):
             return self.conv(P, ff, w[n + ".ff.out+proj_out"], residual=x, append=(t2, None), gn_stats=True)
