@@ -141,6 +141,21 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(const AsArgs s, const Ige
     if (s.e2 > s.e1) issue(s.x2, s.ld2, s.e1, s.e2);
     if (s.e3 > s.e2) issue(s.x3, s.ld3, s.e2, s.e3);
     if (nch * 32 > s.e3) issue(s.x4, s.ld4, s.e3, nch * 32);
+    // bias and LayerNorm column sums of this workgroup's columns [p0 * PW, p1 * PW), into LDS with the tile: read from
+    // global memory per pass they put a vmcnt(0) in front of every epilogue (the compiler cannot count across the K
+    // loop): a drain of the PF * NI weight fragments just requested for the next pass, ~2k cycles per pass
+    if constexpr (!GEN) {
+      float* bl0 = (float*)(smem + nch * BM * 32) + BM * 2 + NW * NI * 32;
+      const int npc = (p1 - p0) * (PW / 256);  // 1 KiB pieces per array
+      for (int idx = wave; idx < 2 * npc; idx += NW) {
+        const bool second = idx >= npc;
+        const int pc = second ? idx - npc : idx;
+        const int col = p0 * PW + pc * 256 + lane * 4;
+        const float* arr = second ? s.ln_u : s.bias;
+        const float* src = (arr && col < s.npad) ? arr + col : (const float*)s.zero;
+        __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(bl0 + (second ? s.ppw * PW : 0) + pc * 256), 16, 0, 0);
+      }
+    }
   }
 
   // ---- 2. this wave's output columns; weight addressing = wave-uniform base (SGPR pair, one per fragment and ring
@@ -174,34 +189,20 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(const AsArgs s, const Ige
   // loop (a dependent load round trip behind the K loop costs ~1 us per pass), or igemm_common.h's general one
   const bool ep_geglu = !GEN && geglu;  // (the host picks GEN = false only for these two)
   const bool ep_plain = !GEN && !geglu;
-  const float* biasp = s.bias ? s.bias : (const float*)s.zero;
-  const unsigned has_b = s.bias ? ~0u : 0u;
-  const float* lnup = s.ln_u ? s.ln_u : (const float*)s.zero;
-  const unsigned has_u = s.ln_u ? ~0u : 0u;
   const f16* resp = s.res ? s.res : s.zero;
   const unsigned has_r = s.res ? ~0u : 0u;
 
-  f32x4 bv[NI], lu[NI];
   f16x4 rr[RA ? MI : 1][NI];
-  auto epi_prefetch = [&](int p) {
+  auto epi_prefetch = [&](int p) {  // (plain epilogue: the residual rows of the pass, requested ahead of its K loop)
     const int nw = col0 + p * PW;
-    if (ep_plain || ep_geglu) {
+    if (ep_plain && RA) {
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const unsigned n = (unsigned)(nw + (geglu2 ? j * 32 : j * 16) + lg * 4);
-        const unsigned nn = n < (unsigned)s.npad ? n : 0u;
-        bv[j] = *(const f32x4*)(biasp + (nn & has_b));
-        lu[j] = *(const f32x4*)(lnup + (nn & has_u));
-      }
-      if (ep_plain && RA) {
+      for (int i = 0; i < MI; ++i) {
+        const unsigned m = (unsigned)min(m0 + i * 16 + lc, s.M - 1);
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          const unsigned m = (unsigned)min(m0 + i * 16 + lc, s.M - 1);
-#pragma unroll
-          for (int j = 0; j < NI; ++j) {
-            const unsigned n = (unsigned)(nw + j * 16 + lg * 4);
-            rr[i][j] = *(const f16x4*)(resp + ((m * (unsigned)s.ldr + (n < (unsigned)s.n_out ? n : 0u)) & has_r));
-          }
+        for (int j = 0; j < NI; ++j) {
+          const unsigned n = (unsigned)(nw + j * 16 + lg * 4);
+          rr[i][j] = *(const f16x4*)(resp + ((m * (unsigned)s.ldr + (n < (unsigned)s.n_out ? n : 0u)) & has_r));
         }
       }
     }
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(const AsArgs s, const Ige
   // ---- 3. folded LayerNorm: {mean, rstd} of the tile's rows, from the resident tile or from the producer's row sums
   float* st = (float*)(smem + nch * BM * 32);  // [BM][2]
   float* red = st + BM * 2;                    // Epi::tile_plain_cp scratch
+  const float* bl = red + NW * NI * 32;        // [2][ppw * PW]: bias | LayerNorm column sums of columns p0 * PW ..
   if (s.ln_u) {
     if (s.lnr_in) {
       if (tid < BM) {  // (Epi::lnr_row: the producer's per-slot row sums)
@@ -339,6 +341,13 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(const AsArgs s, const Ige
       continue;
     }
     if constexpr (!GEN) {
+      f32x4 bv[NI], lu[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int nl = nw - p0 * PW + (geglu2 ? j * 32 : j * 16) + lg * 4;
+        bv[j] = *(const f32x4*)(bl + nl);
+        lu[j] = *(const f32x4*)(bl + s.ppw * PW + nl);
+      }
       if (s.ln_u) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -459,6 +468,8 @@ bool astat_plan(const upk_ctx* ctx, const IgemmArgs& a, int c, int ppw_req, AsPl
   if (ppw > pl->npass) ppw = pl->npass;
   pl->ppw = ppw;
   pl->tiles_n = (pl->npass + ppw - 1) / ppw;
+  pl->lds_bytes += 2 * ppw * PW * 4;  // bias | column sums of the workgroup's columns
+  if (pl->lds_bytes > 160 * 1024) return false;
   return true;
 }
 

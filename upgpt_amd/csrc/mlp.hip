@@ -33,6 +33,7 @@ struct MlpArgs {
   int ldx, ldr, ldy, M, nch1, n1, n2, n2pad, nh;
   int gn_nblk, gn_hw;
   float ln_inv_dim, ln_eps;
+  unsigned long long* dbg;  // dev: s_memtime stamps (UPK_TIMELINE builds)
 };
 #define ML_PIN(v) asm volatile("" ::"s"(v))
 
@@ -50,12 +51,21 @@ __global__ __launch_bounds__(512) void mlp_kernel(const MlpArgs s) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lg = lane >> 4, lc = lane & 15;
+#ifdef UPK_TIMELINE
+  const bool tl = s.dbg && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && (wave == 0 || wave == 4);
+  unsigned long long* tlp = s.dbg + (blockIdx.x == 0 ? 0 : 64) + (wave == 0 ? 0 : 32);
+#define STAMP(i) do { if (tl && lane == 0 && (i) < 32) tlp[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+  STAMP(0);
   const int m0 = blockIdx.x * BM;
   const int nch1 = s.nch1, nh = s.nh, nch2 = nh + nch1;
   // LDS: chunks [0, nh) = h, chunks [nh, nh + nch1) = t2  (the second GEMM's K order), then the row statistics
   f16* const hT = smem;
   f16* const xT = smem + nh * BM * 32;
   float* const st = (float*)(smem + nch2 * BM * 32);  // [BM][2]
+  float* const bl = st + BM * 2;                      // [2][n1]: GEGLU bias, LayerNorm column sums (packed order)
 
   // ---- 1. t2 tile
   {
@@ -69,6 +79,14 @@ __global__ __launch_bounds__(512) void mlp_kernel(const MlpArgs s) {
       const int m = m0 + rg * 16 + r16;
       const f16* src = m < s.M ? s.x + (long)m * s.ldx + kc * 32 + chd * 8 : zsrc;
       __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(xT + (kc * BM + rg * 16) * 32), 16, 0, 0);
+    }
+    // the GEGLU epilogue's operands for every pass, into LDS with the tile: read from global memory per pass they put a
+    // vmcnt(0) in front of each epilogue (the compiler cannot count across the K loop) — a drain of the 14 weight
+    // fragments just requested for the next pass, ~2k cycles per pass in the in-kernel stamps
+    const int nkb = s.n1 >> 8;  // 1 KiB pieces per array (n1 % 256 == 0)
+    for (int idx = wave; idx < 2 * nkb; idx += NW) {
+      const float* src = (idx < nkb ? s.b1 + idx * 256 : s.u1 + (idx - nkb) * 256) + lane * 4;
+      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(bl + idx * 256), 16, 0, 0);
     }
   }
 
@@ -104,21 +122,7 @@ __global__ __launch_bounds__(512) void mlp_kernel(const MlpArgs s) {
       ring[u][1] = *(const f16x8*)(wb2 + 1024 + voff2[u]);
     }
   }
-  // operands of the first pass's epilogue, and of the second GEMM's (requested with the ring: one round trip)
-  const float* b1p = s.b1;
-  const float* u1p = s.u1;
-  f32x4 bv[NI], lu[NI];
-  auto epi1_prefetch = [&](int p) {
-    const int nw = col1 + p * PW;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const unsigned n = (unsigned)(nw + j * 32 + lg * 4);
-      const unsigned nn = n < (unsigned)s.n1 ? n : 0u;
-      bv[j] = *(const f32x4*)(b1p + nn);
-      lu[j] = *(const f32x4*)(u1p + nn);
-    }
-  };
-  if (p1w > 0) epi1_prefetch(0);
+  // operands of the second GEMM's epilogue (requested with the ring: one round trip)
   f32x4 b2v[NI];
   f16x4 rr[MI][NI];
   if (act2) {
@@ -133,7 +137,9 @@ __global__ __launch_bounds__(512) void mlp_kernel(const MlpArgs s) {
       }
     }
   }
+  STAMP(1);
   __syncthreads();  // (t2 tile landed)
+  STAMP(2);
 
   // ---- 3. LayerNorm statistics of the tile's rows (from the resident tile)
   {
@@ -163,13 +169,13 @@ __global__ __launch_bounds__(512) void mlp_kernel(const MlpArgs s) {
   }
   __syncthreads();
 
+  STAMP(3);
   const unsigned la = (unsigned)(lc * 32 + lds_swz(lc, lg) * 8) * 2u;
   const char* const xs = (const char*)xT;
   const char* const hs = (const char*)hT;
 
   // ---- 4. GEGLU passes -> h tile in LDS
   for (int p = 0; p < p1w; ++p) {
-    if (p > 0) epi1_prefetch(p);
     f32x4 acc[MI][NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -198,24 +204,30 @@ __global__ __launch_bounds__(512) void mlp_kernel(const MlpArgs s) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    STAMP(4 + 2 * p);
     // epilogue: folded LayerNorm, bias, v * gelu(g) -> fp16 -> h tile (chunk = hidden column / 32, XOR-swizzled 16-byte
     // pieces like every A tile: this lane's 4 columns are half a piece)
     const int n = col1 + p * PW + lg * 4;            // packed value column
+    const f32x4 bv0 = *(const f32x4*)(bl + n), bv1 = *(const f32x4*)(bl + n + 32);
+    const f32x4 lu0 = *(const f32x4*)(bl + s.n1 + n), lu1 = *(const f32x4*)(bl + s.n1 + n + 32);
     const int oc = (n >> 6) * 32 + (n & 31);         // hidden column
     const int hk = oc >> 5, hq = (oc & 31) >> 3, hh = oc & 7;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const f32x2 mr = *(const f32x2*)(st + 2 * (i * 16 + lc));
-      const f32x4 v = (acc[i][0] - mr[0] * lu[0]) * mr[1] + bv[0];
-      const f32x4 g = (acc[i][1] - mr[0] * lu[1]) * mr[1] + bv[1];
+      const f32x4 v = (acc[i][0] - mr[0] * lu0) * mr[1] + bv0;
+      const f32x4 g = (acc[i][1] - mr[0] * lu1) * mr[1] + bv1;
       f16x4 o;
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] = (f16)upk_geglu_mul(v[k], g[k]);
       const int row = i * 16 + lc;
       *(f16x4*)(hT + (hk * BM + row) * 32 + lds_swz(lc, hq) * 8 + hh) = o;
     }
+    STAMP(5 + 2 * p);
   }
+  STAMP(20);
   __syncthreads();  // (h complete)
+  STAMP(21);
 
   // ---- 5. second GEMM over [h | t2] (LDS chunk order = its K order), epilogue: bias, residual, GroupNorm partials
   if (!act2) return;
@@ -245,6 +257,7 @@ __global__ __launch_bounds__(512) void mlp_kernel(const MlpArgs s) {
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  STAMP(22);
   f32x4 cs[NI], cq[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) cs[j] = cq[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -287,6 +300,11 @@ __global__ __launch_bounds__(512) void mlp_kernel(const MlpArgs s) {
       }
     }
   }
+#ifdef UPK_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(23);
+#endif
+#undef STAMP
 }
 
 }  // namespace
@@ -303,7 +321,8 @@ extern "C" int upk_geglu_mlp_supported(upk_ctx* ctx, const upk_mlp_desc* d) {
   if ((d->ldx & 7) || (d->ld_res & 3) || (d->ldy & 3) || (d->n_out & 3)) return 0;
   const int bm = d->rows_per_wg > 0 ? d->rows_per_wg : 64;
   if (bm != 32 && bm != 64) return 0;
-  if ((size_t)(nch1 + nh) * bm * 64 + (size_t)bm * 8 > 160 * 1024) return 0;
+  if ((2 * d->inner) & 255) return 0;
+  if ((size_t)(nch1 + nh) * bm * 64 + (size_t)bm * 8 + (size_t)d->inner * 16 > 160 * 1024) return 0;
   if (d->gn_stats_ws && (d->hw <= 0 || d->hw % bm || d->hw / bm > UPK_GN_MAX_CHUNKS)) return 0;
   return 1;
 }
@@ -328,7 +347,10 @@ extern "C" int upk_geglu_mlp_f16(upk_ctx* ctx, const upk_mlp_desc* d, upk_stream
   s.gn_nblk = d->hw > 0 ? d->hw / bm : 1;
   s.ln_inv_dim = 1.0f / (float)(d->ln_dim > 0 ? d->ln_dim : d->c);
   s.ln_eps = d->ln_eps;
-  const size_t lds = (size_t)(s.nch1 + s.nh) * bm * 64 + (size_t)bm * 8;
+#ifdef UPK_TIMELINE
+  s.dbg = getenv("UPK_MLP_TL") ? (unsigned long long*)((char*)ctx->ws + ctx->ws_bytes - 4096) : nullptr;
+#endif
+  const size_t lds = (size_t)(s.nch1 + s.nh) * bm * 64 + (size_t)bm * 8 + (size_t)s.n1 * 8;
   void (*fn)(const MlpArgs) = bm == 32 ? mlp_kernel<2, 7> : mlp_kernel<4, 7>;
   static bool attr32 = false, attr64 = false;
   bool& done = bm == 32 ? attr32 : attr64;
