@@ -222,7 +222,7 @@ def test_get_input_and_log_images_vs_reference_fixture():
     assert c["c_crossattn"].shape == (B, 87, 768)
     # text | styles pass through (DummyModel), the SMPL row is a Linear: exact vs fp32-matmul tolerance
     assert torch.equal(c["c_crossattn"][:, :86].cpu(), torch.as_tensor(g["c_crossattn"][:, :86]))
-    assert float((c["c_crossattn"][:, 86].cpu() - torch.as_tensor(g["c_crossattn"][:, 86])).abs().max()) < 1e-4
+    assert float((c["c_crossattn"][:, 86].detach().cpu() - torch.as_tensor(g["c_crossattn"][:, 86])).abs().max()) < 1e-4
     assert torch.equal(c["c_concat"][0].cpu(), torch.as_tensor(g["c_concat"]))
     assert float((torch.nn.functional.avg_pool2d(x.cpu(), 8) - torch.as_tensor(g["x"])).abs().max()) < 1e-6
     z_mode = m.get_first_stage_encoding(m.encode_first_stage(x).mode())
@@ -498,10 +498,10 @@ def test_invalid_shapes_fail_loudly():
         model.apply_model(inp["x_T"].cuda(), torch.tensor([5]).cuda(),
                           {"c_crossattn": inp["c_crossattn"].cuda(), "c_concat": [inp["c_concat"].cuda()]})
     ok = synth.synth_inputs(1, (32, 24), 4, 87, 768, seed=0)
-    with pytest.raises(AssertionError):  # wrong context width
+    with pytest.raises(ValueError):  # wrong context width
         model.model.diffusion_model(torch.cat([ok["x_T"], ok["c_concat"]], 1).cuda(), torch.tensor([5]).cuda(),
                                     context=torch.zeros(1, 87, 512).cuda())
-    with pytest.raises(AssertionError):  # wrong channel count
+    with pytest.raises(ValueError):  # wrong channel count
         model.model.diffusion_model(ok["x_T"].cuda(), torch.tensor([5]).cuda(), context=ok["c_crossattn"].cuda())
 
 

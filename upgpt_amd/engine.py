@@ -265,6 +265,7 @@ class Program:
         self.cls = []
         self.labels = []
         self.keep = []
+        self.flops = []  # algorithmic FLOPs of each op (conv / GEMM launches; 0 elsewhere)
         self.igemm_flops = 0
         self.attn_flops = 0
         self.n_launch = 0
@@ -282,6 +283,7 @@ class Program:
 
     def add(self, fn, *keep, cls="other", label=None):
         self.ops.append(fn)
+        self.flops.append(0)
         self.cls.append(cls)
         self.labels.append(label or cls)
         self.keep.extend(keep)
@@ -630,6 +632,7 @@ class Emitter:
 
             P.add(run, *keep, gamma, beta, ws, armed, cls="igemm_k%d" % ks, label=key)
         P.igemm_flops += 2 * M * pw.n_real * pw.k_real
+        P.flops[-1] = 2 * M * pw.n_real * pw.k_real
         return ret
 
     class GnProvider:
@@ -773,6 +776,7 @@ class Emitter:
         P.add(lambda s: chk(fn(h, C.byref(d), s)), d, t2, x_in, pw1, pw2, out, sws, cls="igemm_k1",
               label="mlp M%d C%d rows%d" % (M, C_, rows))
         P.igemm_flops += 2 * M * (2 * pw1.n_out * C_ + pw2.n_real * (pw1.n_out + C_))
+        P.flops[-1] = 2 * M * (2 * pw1.n_out * C_ + pw2.n_real * (pw1.n_out + C_))
         return out
 
     def attention(self, P, q, ldq, qbs, k, ldk, kbs, vt, vt_ld, out, ldo, obs, B, heads, nq, nkv, dp, scale):
