@@ -182,7 +182,6 @@ __global__ __launch_bounds__(512) void pconv_kernel(const PcArgs pa) {
   const int nslab = pa.nslab;
   // the kernel arguments of the prologue in ONE batch of scalar loads (read lazily they are a chain of ~10 dependent
   // scalar-cache misses before the first DMA, and inside the forward every one of them goes to memory)
-#ifdef UPK_PC_PIN
   asm volatile("" ::"s"(a.p_xcd), "s"(a.tiles_m), "s"(a.tiles_n), "s"(a.tile_rows), "s"(a.p_pw), "s"(a.Ho), "s"(a.Wo), "s"(a.ks),
                "s"(a.zero), "s"(a.npad), "s"(pa.nslab), "s"(a.p_ps), "s"(a.p_cs), "s"(a.cpt), "s"(a.w), "s"(a.p_tpp_log2),
                "s"(a.p_np), "s"(a.HS), "s"(a.WS), "s"(a.gni_mode), "s"(a.c1), "s"(a.c2), "s"(a.M), "s"(a.p_T), "s"(a.p_tab),
@@ -190,7 +189,6 @@ __global__ __launch_bounds__(512) void pconv_kernel(const PcArgs pa) {
   asm volatile("" ::"s"(a.gni_gamma), "s"(a.gni_beta), "s"(a.gni_s1), "s"(a.gni_nblk1), "s"(a.gni_ld1), "s"(a.gni_groups),
                "s"(a.gni_cpg), "s"(a.gni_eps), "s"(a.gni_silu), "s"(a.x1), "s"(a.x2), "s"(a.ld1), "s"(a.ld2), "s"(a.sh_hw),
                "s"(a.sh_w));
-#endif
   static_assert(WM * KW == 4, "4 MFMA waves");
   static_assert(KS % KW == 0, "every K slice gets the same number of chunks per stage");
   constexpr int BN = NI * 16;
