@@ -281,6 +281,38 @@ int upk_geglu_mlp_f16(upk_ctx* ctx, const upk_mlp_desc* d, upk_stream stream);
 /* 1 if upk_geglu_mlp_f16 takes the shape (channel family, LDS budget, row-block geometry), else 0. */
 int upk_geglu_mlp_supported(upk_ctx* ctx, const upk_mlp_desc* d);
 
+/* The cross-attention half of a BasicTransformerBlock (attention.py:257-260 with the context K / V precomputed) as one
+ * launch:  t1 = a1 W_out1^T + b_out1 + t0;  q = LayerNorm(t1) W_q^T;  a2 = softmax(q K^T scale) V per head;
+ * y = a2 W_out2^T + b_out2 + t1.   a1 [m, lda]: self-attention output, heads side by side at the padded head width d;
+ * w_out1 / w_out2: packed [c rows][K = heads * d] (upk_pack_weight with the head padding as column map); w_q: packed
+ * [heads * d rows][K = c] with the LayerNorm affine folded in (as ln_colsum weights); vec = [b_out1 (c) | colsum_q
+ * (heads * d) | bias_q (heads * d) | b_out2 (c)] fp32, zero padded to a multiple of 256 floats; k_ctx [batch * n_kv, ldk],
+ * vt_ctx [batch, heads, d, vt_ld] as upk_attention_f16 takes them (n_kv <= 96 <= vt_ld).  hw = rows per sample (a
+ * multiple of rows_per_wg: 16 or 32, 0 = 32).  Shapes: heads = 8, (c, d) in {(224, 32), (448, 64)}. */
+typedef struct upk_xblock_desc {
+  const void* a1;
+  int32_t lda, m, c, heads, d;
+  const void* t0;
+  int32_t ld_t0;
+  const void* w_out1;
+  const void* w_q;
+  const void* w_out2;
+  const float* vec;
+  float ln_eps;
+  int32_t ln_dim;
+  const void* k_ctx;
+  int32_t ldk, n_kv;
+  const void* vt_ctx;
+  int32_t vt_ld;
+  float scale;
+  void* y;
+  int32_t ldy;
+  int32_t hw, rows_per_wg;
+} upk_xblock_desc;
+int upk_cross_block_f16(upk_ctx* ctx, const upk_xblock_desc* d, upk_stream stream);
+/* 1 if upk_cross_block_f16 takes the shape, else 0. */
+int upk_cross_block_supported(upk_ctx* ctx, const upk_xblock_desc* d);
+
 /* Convenience wrapper: y[M,N] = act(A[M,K] @ W^T + bias) + residual. */
 int upk_gemm_f16(upk_ctx* ctx, const void* a, int lda, int m, int k, const void* w_packed,
                  int n_out, int n_pad, const float* bias, const void* residual, int ld_res,

@@ -1,0 +1,130 @@
+"""Fused cross-attention half of a BasicTransformerBlock (upgpt_amd/csrc/xblock.hip, include/upk.h upk_cross_block_f16)
+through the C ABI against a plain PyTorch fp32 reference of attn1.to_out (+ x) -> norm2 -> attn2 over the context
+(+ x) (attention.py:178-192, 257-260), and the engine's use of it inside the UNet forward against the unfused path."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from upgpt_amd import _lib as L
+from test_ops_gpu import DEV, check, rnd
+
+pytestmark = pytest.mark.gpu
+
+
+def head_cols(heads, dh, dp):
+    """Column map of the padded head layout: packed column h * dp + j <- real column h * dh + j (j < dh), else -1."""
+    m = torch.full((heads * dp,), -1, dtype=torch.int32)
+    for h in range(heads):
+        m[h * dp: h * dp + dh] = torch.arange(h * dh, (h + 1) * dh, dtype=torch.int32)
+    return m
+
+
+@pytest.mark.parametrize("B,hw,c,dh,dp,rows,nkv", [(8, 1024, 224, 28, 32, 32, 87), (2, 64, 224, 28, 32, 16, 87),
+                                                   (3, 256, 448, 56, 64, 32, 77), (8, 256, 448, 56, 64, 16, 96),
+                                                   (1, 32, 224, 28, 32, 32, 1)])
+def test_cross_block_vs_torch(ctx, B, hw, c, dh, dp, rows, nkv):
+    heads = 8
+    M, hd, inner = B * hw, heads * dp, heads * dh
+    a1r = rnd(M, inner, seed=1)                      # self-attention output, real head width
+    t0 = (rnd(M, c, seed=2) * 1.5 + 0.3).half()
+    wo1, bo1 = rnd(c, inner, scale=1 / math.sqrt(inner), seed=3), rnd(c, scale=0.1, seed=4)
+    gamma, beta = 1 + 0.2 * rnd(c, seed=5), 0.1 * rnd(c, seed=6)
+    wq = rnd(inner, c, scale=1 / math.sqrt(c), seed=7)
+    wo2, bo2 = rnd(c, inner, scale=1 / math.sqrt(inner), seed=8), rnd(c, scale=0.1, seed=9)
+    kr, vr = rnd(B, nkv, inner, seed=10), rnd(B, nkv, inner, seed=11)
+    scale = dh ** -0.5
+    cols = head_cols(heads, dh, dp).to(DEV)
+    real = cols >= 0
+
+    def padded(x):  # [..., inner] -> [..., hd] fp16
+        out = torch.zeros(*x.shape[:-1], hd, device=DEV, dtype=torch.float16)
+        out[..., real] = x.half()
+        return out
+
+    a1 = padded(a1r)
+    kc = padded(kr).reshape(B * nkv, hd).contiguous()
+    vt_ld = 96
+    vt = torch.zeros(B, heads, dp, vt_ld, device=DEV, dtype=torch.float16)
+    vt[:, :, :dh, :nkv] = vr.half().reshape(B, nkv, heads, dh).permute(0, 2, 3, 1)
+    # reference (fp32 on the fp16-rounded operands; t1 is rounded to fp16 as the kernel keeps it)
+    t1 = (a1r.half().float() @ wo1.half().float().t() + bo1 + t0.float()).half().float()
+    wqf = (wq * gamma[None, :]).half().float()
+    xn = (t1 - t1.mean(1, keepdim=True)) * torch.rsqrt(t1.var(1, unbiased=False, keepdim=True) + 1e-5)
+    q = (xn @ wqf.t() + wq @ beta).half().float().reshape(B, hw, heads, dh).permute(0, 2, 1, 3)
+    k = kr.half().float().reshape(B, nkv, heads, dh).permute(0, 2, 1, 3)
+    v = vr.half().float().reshape(B, nkv, heads, dh).permute(0, 2, 1, 3)
+    p = torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1)
+    a2 = (p @ v).permute(0, 2, 1, 3).reshape(M, inner).half().float()
+    ref = a2 @ wo2.half().float().t() + bo2 + t1
+    # operands
+    w1p, n1 = ctx.pack_weight(wo1.contiguous(), col_map=cols)
+    w3p, n3 = ctx.pack_weight(wo2.contiguous(), col_map=cols)
+    wqp, nq = ctx.pack_weight((wq * gamma[None, :]).contiguous(), row_map=cols)
+    assert n1 == c and n3 == c and nq == hd
+    uq = torch.zeros(hd, device=DEV); uq[real] = wqf.sum(dim=1)
+    bq = torch.zeros(hd, device=DEV); bq[real] = wq @ beta
+    vec = torch.cat([bo1, uq, bq, bo2])
+    vec = torch.cat([vec, vec.new_zeros(-vec.numel() % 256)]).contiguous()
+    y = torch.zeros(M, c, device=DEV, dtype=torch.float16)
+    d = L.XblockDesc()
+    d.a1, d.lda, d.m, d.c, d.heads, d.d = a1.data_ptr(), hd, M, c, heads, dp
+    d.t0, d.ld_t0 = t0.data_ptr(), c
+    d.w_out1, d.w_q, d.w_out2, d.vec = w1p.data_ptr(), wqp.data_ptr(), w3p.data_ptr(), vec.data_ptr()
+    d.ln_eps, d.ln_dim = 1e-5, c
+    d.k_ctx, d.ldk, d.n_kv = kc.data_ptr(), hd, nkv
+    d.vt_ctx, d.vt_ld, d.scale = vt.data_ptr(), vt_ld, scale
+    d.y, d.ldy, d.hw, d.rows_per_wg = y.data_ptr(), c, hw, rows
+    assert ctx.lib.upk_cross_block_supported(ctx.h, C.byref(d))
+    ctx._chk(ctx.lib.upk_cross_block_f16(ctx.h, C.byref(d), ctx._s()))
+    torch.cuda.synchronize()
+    check(y, ref, tol=8e-3)
+    y2 = torch.zeros_like(y)
+    d.y = y2.data_ptr()
+    ctx._chk(ctx.lib.upk_cross_block_f16(ctx.h, C.byref(d), ctx._s()))
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+
+
+def test_cross_block_refuses_shapes_outside_its_domain(ctx):
+    d = L.XblockDesc()
+    d.m, d.c, d.heads, d.d, d.hw, d.rows_per_wg, d.n_kv, d.vt_ld = 1024, 896, 8, 128, 64, 32, 87, 96
+    d.lda, d.ld_t0, d.ldy, d.ldk = 1024, 896, 896, 1024
+    assert not ctx.lib.upk_cross_block_supported(ctx.h, C.byref(d))
+    d.c, d.d, d.lda, d.ldk, d.ld_t0, d.ldy, d.n_kv = 224, 32, 256, 256, 224, 224, 120
+    assert not ctx.lib.upk_cross_block_supported(ctx.h, C.byref(d))  # more context keys than the kernel covers
+    buf = torch.zeros(16, device=DEV)
+    for f in ("a1", "t0", "w_out1", "w_q", "w_out2", "vec", "k_ctx", "vt_ctx", "y"):
+        setattr(d, f, buf.data_ptr())
+    with pytest.raises(L.UpkError):
+        ctx._chk(ctx.lib.upk_cross_block_f16(ctx.h, C.byref(d), ctx._s()))
+
+
+def test_unet_forward_with_and_without_the_fused_cross_block():
+    """The bbox UNet at the bench shape (B = 8, 32x32): eps with the fused cross-attention half against the unfused
+    launches (UPGPT_XBLOCK=0), same weights and inputs."""
+    import upgpt_amd
+    from upgpt_amd import engine, synth
+
+    def run(mode):
+        old = engine.XBLOCK
+        engine.XBLOCK = mode
+        try:
+            m = upgpt_amd.build_model("bbox")
+            synth.fill_module_(m)
+            m = m.cuda()
+            inp = synth.synth_inputs(8, (32, 32), 4, 87, 768, seed=3, text_only=True)
+            cond = {"c_crossattn": inp["c_crossattn"].cuda(), "c_concat": [inp["c_concat"].cuda()]}
+            t = torch.full((8,), 601, dtype=torch.long, device=DEV)
+            eps = m.apply_model(inp["x_T"].cuda(), t, cond)
+            pl = next(iter(m.model.diffusion_model._plans.values()))
+            return eps.float().cpu(), sum(1 for lab in pl.body.labels if lab.startswith("xblock "))
+        finally:
+            engine.XBLOCK = old
+
+    e1, n1 = run("1")
+    e0, n0 = run("0")
+    assert n0 == 0 and n1 >= 5, (n0, n1)
+    assert float(((e1 - e0) ** 2).mean()) < 1e-5 * max(1.0, float((e0 ** 2).mean()))

@@ -80,6 +80,10 @@ GN_REDUCE_APPLY = os.environ.get("UPGPT_GN_REDUCE_APPLY", "1") == "1"
 # M / rows-per-workgroup covers the chip (the 32x32 level at B = 8), "0" off, "1" wherever the kernel takes the shape
 MLP_FUSE = os.environ.get("UPGPT_MLP_FUSE", "auto")
 MLP_ROWS = int(os.environ.get("UPGPT_MLP_ROWS", "0"))  # rows per workgroup (32 / 64; 0 = by M)
+# fused cross-attention half of a transformer block (csrc/xblock.hip: attn1.to_out -> norm2 -> to_q -> attention over the
+# context -> attn2.to_out, one launch instead of three / four): "auto", "0" off, "1" wherever the kernel takes the shape
+XBLOCK = os.environ.get("UPGPT_XBLOCK", "auto")
+XB_ROWS = int(os.environ.get("UPGPT_XB_ROWS", "0"))  # rows per workgroup (16 / 32; 0 = by M)
 PCONV_ON = PCONV_MODE != "0"
 LN_LAUNCH_US = 3.0  # what a separate LayerNorm launch costs inside the replayed forward (class ablation: 3.8)
 
@@ -779,6 +783,37 @@ class Emitter:
         P.flops[-1] = 2 * M * (2 * pw1.n_out * C_ + pw2.n_real * (pw1.n_out + C_))
         return out
 
+    def cross_block(self, P, a1, t0, t, kc, vtc, cld, heads, dp, scale):
+        """attn1.to_out (+ t0) -> norm2 -> attn2.to_q -> attention over the context -> attn2.to_out (+ t1) as ONE launch
+        (include/upk.h upk_cross_block_f16), or None when the shape is outside the kernel's domain (UPGPT_XBLOCK)."""
+        w = self.pk.w
+        vec = w.get(t + ".xblock.vec")
+        if XBLOCK == "0" or vec is None or t0.C != t0.ld:
+            return None
+        M, C_ = t0.M, t0.C
+        hw = t0.H * t0.W
+        rows = XB_ROWS or (32 if M // 32 >= self.ctx.num_cus else 16)
+        o1, o2, ql = w[t + ".attn1.to_out"], w[t + ".attn2.to_out"], w[t + ".attn2.q_ln"]
+        d = L.XblockDesc()
+        d.a1, d.lda, d.m, d.c, d.heads, d.d = a1.t.data_ptr(), a1.ld, M, C_, heads, dp
+        d.t0, d.ld_t0 = t0.t.data_ptr(), t0.ld
+        d.w_out1, d.w_q, d.w_out2, d.vec = o1.w.data_ptr(), ql.w.data_ptr(), o2.w.data_ptr(), vec.data_ptr()
+        d.ln_eps, d.ln_dim = 1e-5, C_
+        d.k_ctx, d.ldk, d.n_kv = kc.t.data_ptr(), kc.ld, self.n_ctx
+        d.vt_ctx, d.vt_ld, d.scale = vtc.data_ptr(), cld, float(scale)
+        d.hw, d.rows_per_wg = hw, rows
+        if not self.lib.upk_cross_block_supported(self.hctx, C.byref(d)):
+            return None
+        if XBLOCK == "auto" and M // rows < self.ctx.num_cus:
+            return None  # (every workgroup streams the three weights in full: 16x16 level 34.6 us against 32 us unfused)
+        out = Act(self.alloc(M, C_), t0.B, t0.H, t0.W, C_)
+        d.y, d.ldy = out.t.data_ptr(), out.ld
+        fn, h, chk = self.lib.upk_cross_block_f16, self.hctx, self._chk
+        P.add(lambda s: chk(fn(h, C.byref(d), s)), d, a1, t0, o1, o2, ql, vec, kc, vtc, out, cls="attention",
+              label="xblock M%d C%d d%d rows%d" % (M, C_, dp, rows))
+        P.igemm_flops += 2 * M * (o1.k_real * o1.n_real + ql.k_real * ql.n_real + o2.k_real * o2.n_real)
+        return out
+
     def attention(self, P, q, ldq, qbs, k, ldk, kbs, vt, vt_ld, out, ldo, obs, B, heads, nq, nkv, dp, scale):
         fn, h, chk = self.lib.upk_attention_f16, self.hctx, self._chk
         a = (q.data_ptr(), ldq, qbs, k.data_ptr(), ldk, kbs, vt.data_ptr(), vt_ld, out.data_ptr(), ldo, obs, B, heads,
@@ -845,6 +880,11 @@ class PackedUNet:
                 w[t + ".attn2.kv"] = pk.pack([t + ".attn2.to_k", t + ".attn2.to_v"],
                                              row_map=pad_rows_map(2, heads, dh, dp), bias=False, n_out=hd)
                 w[t + ".attn2.to_out"] = pk.pack(t + ".attn2.to_out.0", col_map=to_out_cols)
+                # epilogue vectors of the fused cross-attention half (include/upk.h upk_xblock_desc.vec)
+                o1, o2, ql = w[t + ".attn1.to_out"], w[t + ".attn2.to_out"], w[t + ".attn2.q_ln"]
+                if o1.n_pad == Lr.ch and o2.n_pad == Lr.ch and ql.n_pad == hd:
+                    vec = torch.cat([o1.bias, ql.ln_colsum, ql.bias, o2.bias])
+                    w[t + ".xblock.vec"] = torch.cat([vec, vec.new_zeros(-vec.numel() % 256)]).contiguous()
                 inner = heads * dh
                 w[t + ".ff.out"] = pk.pack(t + ".ff.net.2")
                 for k in ("norm1", "norm2", "norm3"):
@@ -973,9 +1013,13 @@ class UNetPlan(Emitter):
         self.attention(P, qk.t, 2 * hd, HW * 2 * hd, qk.t[:, hd:], 2 * hd, HW * 2 * hd, vt, vt_ld, a1.t, hd, HW * hd,
                        B, heads, HW, HW, dp, scale)
         P.attn_flops += 4 * B * heads * HW * HW * dh
-        t1 = self.conv(P, a1, w[t + ".attn1.to_out"], residual=t0)
         # cross-attention over the (precomputed) context K / V
         kc, vtc, cld = self.kv[n]
+        t2 = self.cross_block(P, a1, t0, t, kc, vtc, cld, heads, dp, scale)
+        if t2 is not None:
+            P.attn_flops += 4 * B * heads * HW * self.n_ctx * dh
+            return self._st_ff(P, Lr, x, t2)
+        t1 = self.conv(P, a1, w[t + ".attn1.to_out"], residual=t0)
         a2 = Act(self.alloc(M, hd), B, x.H, x.W, hd)
         # (pays while there are >= 2 waves per SIMD to hide a wave's serial projection -> scores chain: 32x32 level
         # 16 -> 12 us per block; at 16x16 (1 wave per SIMD, 4x the weight slice per wave) 16 -> 18 us)
@@ -996,7 +1040,13 @@ class UNetPlan(Emitter):
                            self.n_ctx, dp, scale)
         P.attn_flops += 4 * B * heads * HW * self.n_ctx * dh
         t2 = self.conv(P, a2, w[t + ".attn2.to_out"], residual=t1)
-        # GEGLU feed-forward
+        return self._st_ff(P, Lr, x, t2)
+
+    def _st_ff(self, P, Lr, x, t2):
+        """GEGLU feed-forward of the block + the transformer's proj_out (attention.py:261, 330-336)."""
+        w = self.pk.w
+        n = Lr.name
+        t = n + ".transformer_blocks.0"
         fused = self.geglu_mlp(P, t2, x, w[t + ".ff.geglu_ln"], w[n + ".ff.out+proj_out"])
         if fused is not None:
             return fused
