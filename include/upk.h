@@ -313,6 +313,31 @@ int upk_cross_block_f16(upk_ctx* ctx, const upk_xblock_desc* d, upk_stream strea
 /* 1 if upk_cross_block_f16 takes the shape, else 0. */
 int upk_cross_block_supported(upk_ctx* ctx, const upk_xblock_desc* d);
 
+/* The head of a SpatialTransformer (attention.py:330-333, 257) as one launch: t0 = x W_in^T + b_in (x = the GroupNorm
+ * output, proj_in a 1x1 conv), q | k | v = LayerNorm(t0) W_qkv^T.  w_in: packed [c rows][K = c]; w_qkv: packed
+ * [3 heads d rows][K = c] in q | k | v order at the padded head width, LayerNorm affine folded in; vec = [b_in (c) |
+ * colsum_qkv (3 heads d) | bias_qkv (3 heads d)] fp32, zero padded to a multiple of 256 floats.  t0 [m, ld_t0];
+ * qk [m, ld_qk] = q | k; vt [m / hw, heads, d, vt_ld] = v transposed (vt_ld >= hw).  hw = rows per sample, a multiple of
+ * rows_per_wg (16 or 32, 0 = 32).  Shapes: heads = 8, c = 224, d = 32. */
+typedef struct upk_hblock_desc {
+  const void* x;
+  int32_t ldx, m, c, heads, d;
+  const void* w_in;
+  const void* w_qkv;
+  const float* vec;
+  float ln_eps;
+  int32_t ln_dim;
+  void* t0;
+  int32_t ld_t0;
+  void* qk;
+  int32_t ld_qk;
+  void* vt;
+  int32_t vt_ld;
+  int32_t hw, rows_per_wg;
+} upk_hblock_desc;
+int upk_head_block_f16(upk_ctx* ctx, const upk_hblock_desc* d, upk_stream stream);
+int upk_head_block_supported(upk_ctx* ctx, const upk_hblock_desc* d);
+
 /* Convenience wrapper: y[M,N] = act(A[M,K] @ W^T + bias) + residual. */
 int upk_gemm_f16(upk_ctx* ctx, const void* a, int lda, int m, int k, const void* w_packed,
                  int n_out, int n_pad, const float* bias, const void* residual, int ld_res,

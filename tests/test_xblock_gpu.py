@@ -128,3 +128,77 @@ def test_unet_forward_with_and_without_the_fused_cross_block():
     e0, n0 = run("0")
     assert n0 == 0 and n1 >= 5, (n0, n1)
     assert float(((e1 - e0) ** 2).mean()) < 1e-5 * max(1.0, float((e0 ** 2).mean()))
+
+
+@pytest.mark.parametrize("B,hw,rows", [(8, 1024, 32), (2, 64, 16), (1, 32, 32)])
+def test_head_block_vs_torch(ctx, B, hw, rows):
+    """upk_head_block_f16 (proj_in -> norm1 -> q | k | v, V transposed) against fp32 PyTorch."""
+    heads, c, dh, dp = 8, 224, 28, 32
+    M, hd, inner = B * hw, heads * dp, heads * dh
+    x = (rnd(M, c, seed=1) * 1.3).half()
+    wi, bi = rnd(c, c, scale=1 / math.sqrt(c), seed=2), rnd(c, scale=0.1, seed=3)
+    gamma, beta = 1 + 0.2 * rnd(c, seed=4), 0.1 * rnd(c, seed=5)
+    wqkv = rnd(3 * inner, c, scale=1 / math.sqrt(c), seed=6)
+    cols = head_cols(heads, dh, dp).to(DEV)
+    rows3 = torch.cat([torch.where(cols >= 0, cols + i * inner, cols) for i in range(3)]).to(torch.int32)
+    real3 = rows3 >= 0
+    # reference
+    t0 = (x.float() @ wi.half().float().t() + bi).half().float()
+    wf = (wqkv * gamma[None, :]).half().float()
+    xn = (t0 - t0.mean(1, keepdim=True)) * torch.rsqrt(t0.var(1, unbiased=False, keepdim=True) + 1e-5)
+    qkv = xn @ wf.t() + wqkv @ beta
+    # operands
+    w1p, n1 = ctx.pack_weight(wi.contiguous())
+    w2p, n2 = ctx.pack_weight((wqkv * gamma[None, :]).contiguous(), row_map=rows3)
+    assert n1 == c and n2 == 3 * hd
+    u2 = torch.zeros(3 * hd, device=DEV); u2[real3] = wf.sum(dim=1)
+    b2 = torch.zeros(3 * hd, device=DEV); b2[real3] = wqkv @ beta
+    vec = torch.cat([bi, u2, b2])
+    vec = torch.cat([vec, vec.new_zeros(-vec.numel() % 256)]).contiguous()
+    vt_ld = (hw + 31) // 32 * 32
+    t0o = torch.zeros(M, c, device=DEV, dtype=torch.float16)
+    qk = torch.zeros(M, 2 * hd, device=DEV, dtype=torch.float16)
+    vt = torch.zeros(B, heads, dp, vt_ld, device=DEV, dtype=torch.float16)
+    d = L.HblockDesc()
+    d.x, d.ldx, d.m, d.c, d.heads, d.d = x.data_ptr(), c, M, c, heads, dp
+    d.w_in, d.w_qkv, d.vec, d.ln_eps, d.ln_dim = w1p.data_ptr(), w2p.data_ptr(), vec.data_ptr(), 1e-5, c
+    d.t0, d.ld_t0, d.qk, d.ld_qk, d.vt, d.vt_ld = t0o.data_ptr(), c, qk.data_ptr(), 2 * hd, vt.data_ptr(), vt_ld
+    d.hw, d.rows_per_wg = hw, rows
+    assert ctx.lib.upk_head_block_supported(ctx.h, C.byref(d))
+    ctx._chk(ctx.lib.upk_head_block_f16(ctx.h, C.byref(d), ctx._s()))
+    torch.cuda.synchronize()
+    check(t0o, t0, tol=4e-3)
+    ref_qk = torch.zeros(M, 2 * hd, device=DEV)
+    ref_qk[:, real3[: 2 * hd]] = qkv[:, : 2 * inner]
+    check(qk, ref_qk, tol=8e-3)
+    ref_v = torch.zeros(M, hd, device=DEV)
+    ref_v[:, cols >= 0] = qkv[:, 2 * inner:]
+    ref_vt = ref_v.reshape(B, hw, heads, dp).permute(0, 2, 3, 1)
+    check(vt[..., :hw], ref_vt, tol=8e-3)
+    assert float(vt[..., hw:].abs().max()) == 0.0 if vt_ld > hw else True
+
+
+def test_unet_forward_with_and_without_the_fused_head():
+    import upgpt_amd
+    from upgpt_amd import engine, synth
+
+    def run(mode):
+        old = engine.HBLOCK
+        engine.HBLOCK = mode
+        try:
+            m = upgpt_amd.build_model("bbox")
+            synth.fill_module_(m)
+            m = m.cuda()
+            inp = synth.synth_inputs(8, (32, 32), 4, 87, 768, seed=3, text_only=True)
+            cond = {"c_crossattn": inp["c_crossattn"].cuda(), "c_concat": [inp["c_concat"].cuda()]}
+            t = torch.full((8,), 601, dtype=torch.long, device=DEV)
+            eps = m.apply_model(inp["x_T"].cuda(), t, cond)
+            pl = next(iter(m.model.diffusion_model._plans.values()))
+            return eps.float().cpu(), sum(1 for lab in pl.body.labels if lab.startswith("hblock "))
+        finally:
+            engine.HBLOCK = old
+
+    e1, n1 = run("auto")
+    e0, n0 = run("0")
+    assert n0 == 0 and n1 == 5, (n0, n1)
+    assert float(((e1 - e0) ** 2).mean()) < 1e-5 * max(1.0, float((e0 ** 2).mean()))

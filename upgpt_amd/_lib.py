@@ -20,7 +20,7 @@ SYMBOLS = [
     "upk_pack_weight_f16", "upk_packed_weight_bytes", "upk_conv2d_nhwc_f16", "upk_gemm_f16",
     "upk_conv_autotune", "upk_conv_override", "upk_conv_num_configs", "upk_conv_config_name", "upk_conv_gn_fused",
     "upk_pconv_num_configs", "upk_pconv_config_name", "upk_pconv_supported", "upk_conv_ln_rows",
-    "upk_geglu_mlp_f16", "upk_geglu_mlp_supported", "upk_cross_block_f16", "upk_cross_block_supported",
+    "upk_geglu_mlp_f16", "upk_geglu_mlp_supported", "upk_cross_block_f16", "upk_cross_block_supported", "upk_head_block_f16", "upk_head_block_supported",
     "upk_attention_f16", "upk_groupnorm_nhwc_f16", "upk_groupnorm_stats_nhwc_f16", "upk_groupnorm_chunks", "upk_groupnorm_apply_nhwc_f16", "upk_groupnorm_finalize_f32", "upk_groupnorm_ws_bytes",
     "upk_layernorm_f16", "upk_timestep_embed_f16",
     "upk_nchw_f32_to_nhwc_f16", "upk_nhwc_f16_to_nchw_f32", "upk_f32_to_f16", "upk_ddim_step_f32",
@@ -97,6 +97,16 @@ class XblockDesc(C.Structure):
     ]
 
 
+class HblockDesc(C.Structure):
+    """Mirror of struct upk_hblock_desc (include/upk.h)."""
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int32), ("m", C.c_int32), ("c", C.c_int32), ("heads", C.c_int32), ("d", C.c_int32),
+        ("w_in", C.c_void_p), ("w_qkv", C.c_void_p), ("vec", C.c_void_p), ("ln_eps", C.c_float), ("ln_dim", C.c_int32),
+        ("t0", C.c_void_p), ("ld_t0", C.c_int32), ("qk", C.c_void_p), ("ld_qk", C.c_int32),
+        ("vt", C.c_void_p), ("vt_ld", C.c_int32), ("hw", C.c_int32), ("rows_per_wg", C.c_int32),
+    ]
+
+
 _lib = None
 _lib_lock = threading.Lock()
 
@@ -138,6 +148,8 @@ def load_library(path=None):
             "upk_geglu_mlp_supported": (C.c_int, [vp, C.POINTER(MlpDesc)]),
             "upk_cross_block_f16": (C.c_int, [vp, C.POINTER(XblockDesc), vp]),
             "upk_cross_block_supported": (C.c_int, [vp, C.POINTER(XblockDesc)]),
+            "upk_head_block_f16": (C.c_int, [vp, C.POINTER(HblockDesc), vp]),
+            "upk_head_block_supported": (C.c_int, [vp, C.POINTER(HblockDesc)]),
             "upk_attention_f16": (C.c_int, [vp, vp, i32, i64, vp, i32, i64, vp, i32, vp, i32, i64,
                                             i32, i32, i32, i32, i32, f32, vp]),
             "upk_attention_causal_f16": (C.c_int, [vp, vp, i32, i64, vp, i32, i64, vp, i32, vp, i32, i64,

@@ -403,6 +403,200 @@ __global__ __launch_bounds__(512) void xblock_kernel(const XbArgs s) {
 #undef STAMP
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The head of a SpatialTransformer (attention.py:330-333, 257): proj_in -> norm1 -> to_q | to_k | to_v of the
+// self-attention, one launch:  t0 = xn W_in^T + b_in  (xn = the GroupNorm output);  q | k | v = LayerNorm(t0) W_qkv^T.
+// Same scheme as above: G1 on 7 waves (C / 7 columns each, + bias -> t0 tile in LDS and in HBM: the block's residual
+// stream), row statistics of the tile, then three passes of 8 waves x d columns — pass 0 = q, 1 = k, 2 = v of head
+// `wave` — with the weight ring refilled across the passes; v goes out transposed ([B, heads, d, vt_ld], what
+// upk_attention_f16 reads).
+struct HbArgs {
+  const f16* x;      // [M, ldx]
+  const f16* w1;     // packed [C / 32][C][32]
+  const f16* w2;     // packed [C / 32][3 hd][32], LayerNorm affine folded in
+  const f16* zero;
+  const float* vec;  // [b1 (C) | u2 (3 hd) | b2 (3 hd)], padded to a multiple of 256 floats
+  f16* t0;           // [M, ldt0]
+  f16* qk;           // [M, ldqk]: q | k
+  f16* vt;           // [B, heads, d, vt_ld]
+  int ldx, ldt0, ldqk, vt_ld, M, hw, vec_pieces;
+  float ln_inv_dim, ln_eps;
+  unsigned long long* dbg;
+};
+
+template <int MI, int C32, int DP>
+__global__ __launch_bounds__(512) void hblock_kernel(const HbArgs s) {
+  constexpr int NW = XB_NW, BM = MI * 16;
+  constexpr int C = C32 * 32, HD = NW * DP, N2 = 3 * HD;
+  static_assert(C32 % 7 == 0, "C = 7 waves x NI1 fragments");
+  constexpr int NI1 = C32 * 2 / 7;
+  constexpr int NIQ = DP / 16;
+  constexpr int PF = 7;
+  static_assert(C32 % PF == 0, "ring depth");
+  extern __shared__ __attribute__((aligned(16))) f16 smem[];
+  XB_PIN(s.x); XB_PIN(s.w1); XB_PIN(s.w2); XB_PIN(s.zero); XB_PIN(s.vec); XB_PIN(s.t0); XB_PIN(s.qk); XB_PIN(s.vt);
+  XB_PIN(s.ldx); XB_PIN(s.ldt0); XB_PIN(s.ldqk); XB_PIN(s.vt_ld); XB_PIN(s.M); XB_PIN(s.hw); XB_PIN(s.vec_pieces);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lg = lane >> 4, lc = lane & 15;
+#ifdef UPK_TIMELINE
+  const bool tl = s.dbg && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && (wave == 0 || wave == 4);
+  unsigned long long* tlp = s.dbg + (blockIdx.x == 0 ? 0 : 64) + (wave == 0 ? 0 : 32);
+#define STAMP(i) do { if (tl && lane == 0 && (i) < 32) tlp[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+  STAMP(0);
+  const int m0 = blockIdx.x * BM;
+  const int b = m0 / s.hw;
+  const int tok0 = m0 - b * s.hw;
+  f16* const aT = smem;                            // [C32][BM][32]  xn
+  f16* const tT = smem + C32 * BM * 32;            // [C32][BM][32]  t0
+  float* const st = (float*)(tT + C32 * BM * 32);  // [BM][2]
+  float* const bl = st + BM * 2;
+  const float* const bl_b1 = bl;
+  const float* const bl_u2 = bl + C;
+  const float* const bl_b2 = bl + C + N2;
+  {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const int r16 = lane >> 2;
+    const int chd = (lane & 3) ^ ((-(lane >> 4)) & 3);
+    const f16* zsrc = s.zero + (lane & 3) * 8;
+    for (int idx = wave; idx < C32 * MI; idx += NW) {
+      const int kc = idx / MI, rg = idx - kc * MI;
+      const int m = m0 + rg * 16 + r16;
+      const f16* src = m < s.M ? s.x + (long)m * s.ldx + kc * 32 + chd * 8 : zsrc;
+      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(aT + (kc * BM + rg * 16) * 32), 16, 0, 0);
+    }
+    for (int idx = wave; idx < s.vec_pieces; idx += NW)
+      __builtin_amdgcn_global_load_lds((glb_ptr)(s.vec + idx * 256 + lane * 4), (lds_ptr)(bl + idx * 256), 16, 0, 0);
+  }
+  const bool act1 = wave < 7;
+  const int colw = (act1 ? wave : 6) * NI1 * 16;  // (wave 7: wave 6's columns, results dropped — one instruction stream)
+  const int colq = wave * DP;
+  const unsigned ks1 = (unsigned)C * 64u, ks2 = (unsigned)N2 * 64u;
+  const unsigned loff = (unsigned)(lc * 32 + lg * 8) * 2u;
+  const char* const wb1 = (const char*)s.w1 + (size_t)colw * 64;
+  const char* const wb2 = (const char*)s.w2 + (size_t)colq * 64;
+  f16x8 ring1[PF][NI1];
+  __builtin_amdgcn_sched_barrier(0);
+  xb_fill<NI1, PF>(ring1, wb1, ks1, loff);
+  __builtin_amdgcn_sched_barrier(0);
+  STAMP(1);
+  static_assert(PF * NI1 < 64, "vmcnt range");
+  __builtin_amdgcn_s_waitcnt(((PF * NI1) & 15) | (((PF * NI1) >> 4) << 14) | 0x0070);  // (see xblock_kernel)
+  __builtin_amdgcn_s_barrier();
+  STAMP(2);
+  f16x8 ring2[PF][NIQ];
+  xb_fill<NIQ, PF>(ring2, wb2, ks2, loff);
+  __builtin_amdgcn_sched_barrier(0);
+
+  const unsigned la = (unsigned)(lc * 32 + lds_swz(lc, lg) * 8) * 2u;
+  auto tile_at = [&](f16* T, int row, int n) -> f16* {
+    return T + ((n >> 5) * BM + row) * 32 + lds_swz(row & 15, (n & 31) >> 3) * 8 + (n & 7);
+  };
+
+  // ---- G1: t0 = xn W1^T + b1 -> LDS and HBM
+  {
+    f32x4 acc[MI][NI1];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI1; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    xb_gemm<MI, NI1, PF, C32, BM>(acc, ring1, wb1, ks1, loff, (const char*)aT + la);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + i * 16 + lc;
+      const bool ok = m < s.M && act1;
+      f16* trow = s.t0 + (unsigned)(m < s.M ? m : 0) * (unsigned)s.ldt0;
+#pragma unroll
+      for (int j = 0; j < NI1; ++j) {
+        const int n = colw + j * 16 + lg * 4;
+        const f32x4 bv = *(const f32x4*)(bl_b1 + n);
+        f16x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (f16)(acc[i][j][k] + bv[k]);
+        if (act1) *(f16x4*)tile_at(tT, i * 16 + lc, n) = o;
+        if (ok) *(f16x4*)(trow + n) = o;
+      }
+    }
+  }
+  STAMP(3);
+  xb_lds_barrier();
+  STAMP(4);
+  {
+    constexpr int LPR = 512 / BM;
+    const int row = tid / LPR, part = tid - row * LPR;
+    float s1 = 0.f, s2 = 0.f;
+    const f16x2 one2 = {(f16)1.f, (f16)1.f};
+    for (int q = part; q < C32 * 4; q += LPR) {
+      const f16x8 v = *(const f16x8*)(tT + ((q >> 2) * BM + row) * 32 + (q & 3) * 8);
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const f16x2 xx = {v[2 * h], v[2 * h + 1]};
+        s1 = __builtin_amdgcn_fdot2(xx, one2, s1, false);
+        s2 = __builtin_amdgcn_fdot2(xx, xx, s2, false);
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) {
+      s1 += __shfl_xor(s1, o);
+      s2 += __shfl_xor(s2, o);
+    }
+    if (part == 0) {
+      const float mu = s1 * s.ln_inv_dim;
+      st[2 * row] = mu;
+      st[2 * row + 1] = rsqrtf(fmaxf(s2 * s.ln_inv_dim - mu * mu, 0.f) + s.ln_eps);
+    }
+  }
+  xb_lds_barrier();
+  STAMP(5);
+
+  // ---- G2: three passes (q, k, v of head `wave`), the ring refilled with the next pass's weights as it drains
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    f32x4 acc[MI][NIQ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NIQ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    static_assert(C32 == PF, "one ring block per pass");
+    if (p < 2) xb_block<MI, NIQ, PF, BM, true>(acc, ring2, wb2 + (size_t)(p + 1) * HD * 64, ks2, loff, (const char*)tT + la);
+    else xb_block<MI, NIQ, PF, BM, false>(acc, ring2, wb2, ks2, loff, (const char*)tT + la);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const f32x2 mr = *(const f32x2*)(st + 2 * (i * 16 + lc));
+      const int m = m0 + i * 16 + lc;
+      const bool ok = m < s.M;
+#pragma unroll
+      for (int j = 0; j < NIQ; ++j) {
+        const int n = p * HD + colq + j * 16 + lg * 4;
+        const f32x4 v = (acc[i][j] - mr[0] * *(const f32x4*)(bl_u2 + n)) * mr[1] + *(const f32x4*)(bl_b2 + n);
+        if (p < 2) {
+          f16x4 o;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = (f16)v[k];
+          if (ok) *(f16x4*)(s.qk + (unsigned)m * (unsigned)s.ldqk + n) = o;
+        } else if (ok) {
+          f16* dst = s.vt + ((long)(b * NW + wave) * DP + j * 16 + lg * 4) * s.vt_ld + tok0 + i * 16 + lc;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) dst[(unsigned)k * (unsigned)s.vt_ld] = (f16)v[k];
+        }
+      }
+    }
+    STAMP(6 + p);
+  }
+#ifdef UPK_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(10);
+#endif
+#undef STAMP
+}
+
 }  // namespace
 }  // namespace upkd
 
@@ -472,4 +666,42 @@ extern "C" int upk_cross_block_f16(upk_ctx* ctx, const upk_xblock_desc* d, upk_s
   upk_prof_scope prof(ctx, UPK_CLS_ATTN, stream);
   hipLaunchKernelGGL(cfg->fn, dim3(d->m / bm), dim3(512), lds, stream, s);
   return upk_check_launch(ctx, "cross_block");
+}
+
+extern "C" int upk_head_block_supported(upk_ctx* ctx, const upk_hblock_desc* d) {
+  if (!ctx || !d) return 0;
+  if (d->heads != XB_NW || d->c != 224 || d->d != 32) return 0;
+  const int bm = d->rows_per_wg > 0 ? d->rows_per_wg : 32;
+  if (bm != 32 && bm != 16) return 0;
+  if (d->hw <= 0 || d->hw % bm || d->m % d->hw || d->vt_ld < d->hw) return 0;
+  if ((d->ldx & 7) || (d->ld_t0 & 3) || (d->ld_qk & 3)) return 0;
+  return 1;
+}
+
+extern "C" int upk_head_block_f16(upk_ctx* ctx, const upk_hblock_desc* d, upk_stream stream_) {
+  if (!ctx || !d) return UPK_EINVAL;
+  if (!d->x || !d->w_in || !d->w_qkv || !d->vec || !d->t0 || !d->qk || !d->vt)
+    return upk_fail(ctx, UPK_EINVAL, "head_block: null operand");
+  if (!upk_head_block_supported(ctx, d))
+    return upk_fail(ctx, UPK_ESHAPE, "head_block: shape outside the fused kernel's domain (c=%d d=%d heads=%d)", d->c, d->d,
+                    d->heads);
+  hipStream_t stream = (hipStream_t)stream_;
+  HbArgs s;
+  memset(&s, 0, sizeof(s));
+  s.x = (const f16*)d->x, s.w1 = (const f16*)d->w_in, s.w2 = (const f16*)d->w_qkv, s.zero = (const f16*)ctx->zero_page;
+  s.vec = d->vec, s.t0 = (f16*)d->t0, s.qk = (f16*)d->qk, s.vt = (f16*)d->vt;
+  s.ldx = d->ldx, s.ldt0 = d->ld_t0, s.ldqk = d->ld_qk, s.vt_ld = d->vt_ld, s.M = d->m, s.hw = d->hw;
+  const int hd = d->heads * d->d;
+  s.vec_pieces = (d->c + 6 * hd + 255) / 256;
+  s.ln_inv_dim = 1.0f / (float)(d->ln_dim > 0 ? d->ln_dim : d->c);
+  s.ln_eps = d->ln_eps;
+#ifdef UPK_TIMELINE
+  s.dbg = getenv("UPK_XB_TL") ? (unsigned long long*)((char*)ctx->ws + ctx->ws_bytes - 4096) : nullptr;
+#endif
+  const int bm = d->rows_per_wg > 0 ? d->rows_per_wg : 32;
+  void (*fn)(const HbArgs) = bm == 32 ? hblock_kernel<2, 7, 32> : hblock_kernel<1, 7, 32>;
+  const size_t lds = (size_t)2 * (d->c / 32) * bm * 64 + (size_t)bm * 8 + (size_t)s.vec_pieces * 1024;
+  upk_prof_scope prof(ctx, UPK_CLS_IGEMM, stream);
+  hipLaunchKernelGGL(fn, dim3(d->m / bm), dim3(512), lds, stream, s);
+  return upk_check_launch(ctx, "head_block");
 }

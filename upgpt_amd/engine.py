@@ -84,6 +84,8 @@ MLP_ROWS = int(os.environ.get("UPGPT_MLP_ROWS", "0"))  # rows per workgroup (32 
 # context -> attn2.to_out, one launch instead of three / four): "auto", "0" off, "1" wherever the kernel takes the shape
 XBLOCK = os.environ.get("UPGPT_XBLOCK", "auto")
 XB_ROWS = int(os.environ.get("UPGPT_XB_ROWS", "0"))  # rows per workgroup (16 / 32; 0 = by M)
+# fused head of a SpatialTransformer (csrc/xblock.hip hblock_kernel: proj_in -> norm1 -> q | k | v, one launch instead of two)
+HBLOCK = os.environ.get("UPGPT_HBLOCK", "auto")
 PCONV_ON = PCONV_MODE != "0"
 LN_LAUNCH_US = 3.0  # what a separate LayerNorm launch costs inside the replayed forward (class ablation: 3.8)
 
@@ -783,6 +785,44 @@ class Emitter:
         P.flops[-1] = 2 * M * (2 * pw1.n_out * C_ + pw2.n_real * (pw1.n_out + C_))
         return out
 
+    def head_block_ok(self, x, t, heads, dp, qk, vt_ld):
+        """Whether head_block takes the transformer input x (shape inside the kernel's domain, UPGPT_HBLOCK)."""
+        if HBLOCK == "0" or (t + ".hblock.vec") not in self.pk.w or x.C % 32:
+            return False
+        rows = XB_ROWS or 32
+        d = L.HblockDesc()
+        d.ldx, d.m, d.c, d.heads, d.d = x.C, x.M, x.C, heads, dp
+        d.ld_t0, d.ld_qk, d.vt_ld, d.hw, d.rows_per_wg = x.C, qk.ld, vt_ld, x.H * x.W, rows
+        if not self.lib.upk_head_block_supported(self.hctx, C.byref(d)):
+            return False
+        return HBLOCK == "1" or x.M // rows >= self.ctx.num_cus
+
+    def head_block(self, P, xn, n, t, heads, dp, qk, vt, vt_ld):
+        """proj_in -> norm1 -> q | k | v as ONE launch (include/upk.h upk_head_block_f16) on the GroupNorm output xn;
+        returns t0.  Call head_block_ok first."""
+        w = self.pk.w
+        vec = w[t + ".hblock.vec"]
+        M, C_ = xn.M, xn.C
+        hw = xn.H * xn.W
+        rows = XB_ROWS or 32
+        pi, qkv = w[n + ".proj_in"], w[t + ".attn1.qkv_ln"]
+        d = L.HblockDesc()
+        d.x, d.ldx, d.m, d.c, d.heads, d.d = xn.t.data_ptr(), xn.ld, M, C_, heads, dp
+        d.w_in, d.w_qkv, d.vec = pi.w.data_ptr(), qkv.w.data_ptr(), vec.data_ptr()
+        d.ln_eps, d.ln_dim = 1e-5, C_
+        d.qk, d.ld_qk, d.vt, d.vt_ld = qk.t.data_ptr(), qk.ld, vt.data_ptr(), vt_ld
+        d.hw, d.rows_per_wg = hw, rows
+        require(self.lib.upk_head_block_supported(self.hctx, C.byref(d)), "head_block: unsupported shape", RuntimeError)
+        t0 = Act(self.alloc(M, C_), xn.B, xn.H, xn.W, C_)
+        d.t0, d.ld_t0 = t0.t.data_ptr(), t0.ld
+        fn, h, chk = self.lib.upk_head_block_f16, self.hctx, self._chk
+        P.add(lambda s: chk(fn(h, C.byref(d), s)), d, xn, pi, qkv, vec, t0, qk, vt, cls="igemm_k1",
+              label="hblock M%d C%d d%d rows%d" % (M, C_, dp, rows))
+        fl = 2 * M * (pi.k_real * pi.n_real + qkv.k_real * qkv.n_real)
+        P.igemm_flops += fl
+        P.flops[-1] = fl
+        return t0
+
     def cross_block(self, P, a1, t0, t, kc, vtc, cld, heads, dp, scale):
         """attn1.to_out (+ t0) -> norm2 -> attn2.to_q -> attention over the context -> attn2.to_out (+ t1) as ONE launch
         (include/upk.h upk_cross_block_f16), or None when the shape is outside the kernel's domain (UPGPT_XBLOCK)."""
@@ -880,6 +920,11 @@ class PackedUNet:
                 w[t + ".attn2.kv"] = pk.pack([t + ".attn2.to_k", t + ".attn2.to_v"],
                                              row_map=pad_rows_map(2, heads, dh, dp), bias=False, n_out=hd)
                 w[t + ".attn2.to_out"] = pk.pack(t + ".attn2.to_out.0", col_map=to_out_cols)
+                # epilogue vectors of the fused head (include/upk.h upk_hblock_desc.vec)
+                pi, qkv = w[n + ".proj_in"], w[t + ".attn1.qkv_ln"]
+                if pi.n_pad == Lr.ch and qkv.n_pad == 3 * hd and pi.ksize == 1:
+                    vec = torch.cat([pi.bias, qkv.ln_colsum, qkv.bias])
+                    w[t + ".hblock.vec"] = torch.cat([vec, vec.new_zeros(-vec.numel() % 256)]).contiguous()
                 # epilogue vectors of the fused cross-attention half (include/upk.h upk_xblock_desc.vec)
                 o1, o2, ql = w[t + ".attn1.to_out"], w[t + ".attn2.to_out"], w[t + ".attn2.q_ln"]
                 if o1.n_pad == Lr.ch and o2.n_pad == Lr.ch and ql.n_pad == hd:
@@ -1002,13 +1047,18 @@ class UNetPlan(Emitter):
         dp = head_pad(dh)
         hd = heads * dp
         scale = dh ** -0.5
-        t0 = self.conv(P, x, w[n + ".proj_in"], gn=(*v[n + ".norm"], 1e-6, False, self.gn_ws))
         # self-attention
         qk = Act(self.alloc(M, 2 * hd), B, x.H, x.W, 2 * hd)
         vt_ld = _rup(HW, 32)
         vt = self.alloc(B, heads, dp, vt_ld, zero=True)
-        self.ln_linear(P, t0, t + ".attn1.qkv", t + ".norm1", out=qk,  # norm1 -> q|k|v (attention.py:203,212)
-                       vt=dict(t=vt, heads=heads, dhead=dp, ld=vt_ld, tokens=HW, **{"from": 2 * hd}))
+        t0 = None
+        if not PCONV_ON and self.head_block_ok(x, t, heads, dp, qk, vt_ld):
+            xn = self.groupnorm(P, x, *v[n + ".norm"], 1e-6, False, self.gn_ws)
+            t0 = self.head_block(P, xn, n, t, heads, dp, qk, vt, vt_ld)
+        if t0 is None:
+            t0 = self.conv(P, x, w[n + ".proj_in"], gn=(*v[n + ".norm"], 1e-6, False, self.gn_ws))
+            self.ln_linear(P, t0, t + ".attn1.qkv", t + ".norm1", out=qk,  # norm1 -> q|k|v (attention.py:203,212)
+                           vt=dict(t=vt, heads=heads, dhead=dp, ld=vt_ld, tokens=HW, **{"from": 2 * hd}))
         a1 = Act(self.alloc(M, hd), B, x.H, x.W, hd)
         self.attention(P, qk.t, 2 * hd, HW * 2 * hd, qk.t[:, hd:], 2 * hd, HW * 2 * hd, vt, vt_ld, a1.t, hd, HW * hd,
                        B, heads, HW, HW, dp, scale)
