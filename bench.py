@@ -450,9 +450,11 @@ def main():
         n_api, n_k = prof["igemm"]["launches_per_fwd"], prof["igemm"]["kernels_per_fwd"]
         result["roofline"] = {
             "bound": "mfma",
-            "kernel": "igemm_ws_kernel<*> + igemm_kernel<*> + igemm_as_kernel<*> + mlp_kernel<*> + igemm_reduce[_gn|_gnapply]_kernel "
+            "kernel": "igemm_ws_kernel<*> + igemm_kernel<*> + igemm_as_kernel<*> + mlp_kernel<*> + hblock_kernel<*> + "
+                      "xblock_kernel<*> + igemm_reduce[_gn|_gnapply]_kernel "
                       "(implicit-GEMM conv / Linear in every tile configuration, the A-stationary Linears, the fused "
-                      "feed-forward tail, with the split-K reduce passes and the GroupNorm work they carry): %d conv/GEMM "
+                      "row-chain kernels of the 32x32-level transformer blocks (head, cross-attention half, feed-forward "
+                      "tail), with the split-K reduce passes and the GroupNorm work they carry): %d conv/GEMM "
                       "launches = %d kernels per UNet forward" % (n_api, n_k),
             "method": "graph-replay difference: (forward) - (forward without the class), HIP events on the launch stream; "
                       "GroupNorm / LayerNorm work done inside a conv/GEMM launch (split-K reduce pass that normalises, "

@@ -159,27 +159,6 @@ typedef struct upk_conv_desc {
   const void* x4;
   int32_t c3, c4;
   int32_t ld3, ld4;
-  /* A-stationary "patch" kernel (csrc/pconv.hip), selected with pc_enable != 0 (stride 1, no upsample, no split-K,
-   * no folded LayerNorm): an M tile = whole output image rows of ONE sample; its input patch (+ the 3x3 halo) is
-   * staged once in LDS through registers and the MFMA waves walk the ksize^2 taps out of LDS while only the weights
-   * stream through the LDS-DMA ring (one fill per input pixel instead of nine).  pc_cfg - 1 = tile configuration
-   * (0: built-in choice), upk_pconv_num_configs / upk_pconv_config_name enumerate them.
-   * GroupNorm (+ SiLU) of the INPUT folded into the staging pass — ResBlock in_layers / out_layers
-   * (openaimodel.py:255-275: GroupNorm32 -> SiLU -> conv3x3), SpatialTransformer.norm -> proj_in
-   * (attention.py:250-256):  x1 | x2 are the UN-normalised tensors, gni_gamma / gni_beta the affine over the
-   * c1 + c2 concatenated channels, and the statistics come from partial sums a producer left behind:
-   *   gni_mode 1: per-(chunk, group) partials [batch][gni_nblk1][gni_groups][2] as upk_groupnorm_nhwc_f16's first
-   *               pass / a split-K reduce pass write them (any number of sources);
-   *   gni_mode 2: per-(row block, channel) partials [batch][nblk][2][ld] of each source's producer epilogue.
-   * Zero padding is applied AFTER the normalisation, as F.conv2d on the normalised tensor does. */
-  int32_t pc_enable, pc_cfg;
-  int32_t gni_mode, gni_silu, gni_groups;
-  float gni_eps;
-  const float* gni_gamma;
-  const float* gni_beta;
-  const float* gni_stats1;
-  const float* gni_stats2;
-  int32_t gni_nblk1, gni_ld1, gni_nblk2, gni_ld2;
   /* GroupNorm (+ SiLU) of the OUTPUT applied by the split-K reduce pass (gn_fused mode 3): when this launch splits
    * K (tuned / cost-model choice) and its epilogue is plain (bias + timestep row vector + residual -> fp16 NHWC),
    * the reduce pass runs one workgroup per (sample, group): it sums the slabs, writes y (unless gno_skip_y: nobody
@@ -240,13 +219,6 @@ int upk_groupnorm_finalize_f32(upk_ctx* ctx, const float* partials, int nblk, in
 /* Number of column slots upk_conv2d_nhwc_f16(d) will fill in d->ln_rows_out (0: none — the launch splits K across workgroups or has no
  * plain epilogue).  Nothing is enqueued. */
 int upk_conv_ln_rows(upk_ctx* ctx, const upk_conv_desc* d, int* slots);
-
-/* Tile configurations of the A-stationary patch kernel (upk_conv_desc.pc_enable / pc_cfg). */
-int upk_pconv_num_configs(void);
-const char* upk_pconv_config_name(int cfg);
-/* 1 if upk_conv2d_nhwc_f16 would run `d` on the patch kernel (with d->pc_enable set), 0 if the shape is outside
- * its domain (the launch then falls back to the implicit-GEMM kernels and REFUSES gni_mode != 0). */
-int upk_pconv_supported(upk_ctx* ctx, const upk_conv_desc* d);
 
 /* Fused feed-forward tail of a SpatialTransformer block — BasicTransformerBlock.norm3 -> FeedForward (GEGLU, erf GELU)
  * -> + residual (attention.py:42-64, 215) followed by SpatialTransformer.proj_out -> + x_in (attention.py:259-261) —
@@ -428,8 +400,7 @@ int upk_groupnorm_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int ld1, const 
                            float* stats_ws, upk_stream stream);
 size_t upk_groupnorm_ws_bytes(int batch, int hw);
 /* First half of upk_groupnorm_nhwc_f16 only: the per-(chunk, group) partial sums [batch][nchunks][groups][2]
- * (nchunks = *nchunks of upk_groupnorm_chunks(hw)) for a consumer that normalises on the fly
- * (upk_conv_desc.gni_mode 1). */
+ * (nchunks = *nchunks of upk_groupnorm_chunks(hw)). */
 int upk_groupnorm_stats_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* x2, int c2, int ld2,
                                  int batch, int hw, int groups, float* stats_ws, upk_stream stream);
 int upk_groupnorm_chunks(int hw);

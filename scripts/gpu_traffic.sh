@@ -13,10 +13,10 @@ raw = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob("/tmp/pmc_%s/**/*counter_collection.csv" % c, recursive=True)[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == c]
-    ig = [r for r in rows if "igemm" in r["Kernel_Name"] or "pconv" in r["Kernel_Name"] or "mlp_kernel" in r["Kernel_Name"]]
+    ig = [r for r in rows if "igemm" in r["Kernel_Name"] or "mlp_kernel" in r["Kernel_Name"] or "hblock_kernel" in r["Kernel_Name"] or "xblock_kernel" in r["Kernel_Name"]]
     main = [r for r in ig if "reduce" not in r["Kernel_Name"]]
     # the library's own per-forward kernels (the run also builds the model: weight packing, torch fills, rocBLAS)
-    fwd = [r for r in rows if any(t in r["Kernel_Name"] for t in ("igemm", "pconv", "mlp_kernel", "attn_", "gn_", "layernorm_kernel", "ddim_step"))]
+    fwd = [r for r in rows if any(t in r["Kernel_Name"] for t in ("igemm", "mlp_kernel", "hblock_kernel", "xblock_kernel", "attn_", "gn_", "layernorm_kernel", "ddim_step"))]
     raw[c] = dict(kb_igemm=sum(float(r["Counter_Value"]) for r in ig), launches=len(main),
                   kb_all=sum(float(r["Counter_Value"]) for r in fwd))
 L = raw["FETCH_SIZE"]["launches"]
@@ -25,7 +25,7 @@ print(json.dumps({
     "round": 3, "commit": sys.argv[2],
     "kernel_sources_sha256": open(__import__("os").environ["GRAFT_REPO_ROOT"] + "/upgpt_amd/libupk.so.sha256").read().strip(),
     "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python scripts/fwd_replay.py 32 32 %d (scripts/gpu_traffic.sh)" % N,
-    "kernel_class": "igemm_ws_kernel<*> + igemm_kernel<*> + igemm_as_kernel<*> + mlp_kernel<*> + igemm_reduce[_gn|_gnapply]_kernel (+ pconv_kernel<*> when enabled); per conv/GEMM launch incl. its reduce pass",
+    "kernel_class": "igemm_ws_kernel<*> + igemm_kernel<*> + igemm_as_kernel<*> + mlp_kernel<*> + hblock_kernel<*> + xblock_kernel<*> + igemm_reduce[_gn|_gnapply]_kernel; per conv/GEMM launch incl. its reduce pass",
     "launches": L, "fetch_size_kb_per_launch_raw": fetch, "write_size_kb_per_launch_raw": write,
     "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE as reported; KB -> x1024; Infinity-Cache hits are included (fabric-side counters)",
     "bytes_per_launch": (2 * fetch + write) * 1024.0,

@@ -69,7 +69,7 @@ def replay_ms():
 body = set(id(k) for k in (vp.prog.keep if VAE else pl.body.keep))
 groups = {}
 for d, key in (vp.convs if VAE else pl.convs):
-    if id(d) in body and not d.pc_enable:
+    if id(d) in body:
         groups.setdefault(key, []).append(d)
 NOISE = 0.004 if VAE else 0.0015
 print("shapes in the forward:", len(groups), "launch descriptors:", sum(len(v) for v in groups.values()), flush=True)

@@ -19,7 +19,7 @@ SYMBOLS = [
     "upk_version", "upk_create", "upk_destroy", "upk_last_error", "upk_set_workspace", "upk_num_cus",
     "upk_pack_weight_f16", "upk_packed_weight_bytes", "upk_conv2d_nhwc_f16", "upk_gemm_f16",
     "upk_conv_autotune", "upk_conv_override", "upk_conv_num_configs", "upk_conv_config_name", "upk_conv_gn_fused",
-    "upk_pconv_num_configs", "upk_pconv_config_name", "upk_pconv_supported", "upk_conv_ln_rows",
+    "upk_conv_ln_rows",
     "upk_geglu_mlp_f16", "upk_geglu_mlp_supported", "upk_cross_block_f16", "upk_cross_block_supported", "upk_head_block_f16", "upk_head_block_supported",
     "upk_attention_f16", "upk_groupnorm_nhwc_f16", "upk_groupnorm_stats_nhwc_f16", "upk_groupnorm_chunks", "upk_groupnorm_apply_nhwc_f16", "upk_groupnorm_finalize_f32", "upk_groupnorm_ws_bytes",
     "upk_layernorm_f16", "upk_timestep_embed_f16",
@@ -62,10 +62,6 @@ class ConvDesc(C.Structure):
         ("gn_stats_ws", C.c_void_p), ("gn_groups", C.c_int32),
         ("x3", C.c_void_p), ("x4", C.c_void_p),
         ("c3", C.c_int32), ("c4", C.c_int32), ("ld3", C.c_int32), ("ld4", C.c_int32),
-        ("pc_enable", C.c_int32), ("pc_cfg", C.c_int32),
-        ("gni_mode", C.c_int32), ("gni_silu", C.c_int32), ("gni_groups", C.c_int32), ("gni_eps", C.c_float),
-        ("gni_gamma", C.c_void_p), ("gni_beta", C.c_void_p), ("gni_stats1", C.c_void_p), ("gni_stats2", C.c_void_p),
-        ("gni_nblk1", C.c_int32), ("gni_ld1", C.c_int32), ("gni_nblk2", C.c_int32), ("gni_ld2", C.c_int32),
         ("gno_gamma", C.c_void_p), ("gno_beta", C.c_void_p), ("gno_y", C.c_void_p), ("gno_eps", C.c_float),
         ("gno_silu", C.c_int32), ("gno_ld", C.c_int32), ("gno_skip_y", C.c_int32),
         ("ln_rows_out", C.c_void_p), ("ln_rows_in", C.c_void_p), ("ln_rows_slots", C.c_int32),
@@ -140,9 +136,6 @@ def load_library(path=None):
             "upk_conv_override": (C.c_int, [vp, i32, i32]),
             "upk_conv_num_configs": (C.c_int, []),
             "upk_conv_config_name": (C.c_char_p, [i32]),
-            "upk_pconv_num_configs": (C.c_int, []),
-            "upk_pconv_config_name": (C.c_char_p, [i32]),
-            "upk_pconv_supported": (C.c_int, [vp, C.POINTER(ConvDesc)]),
             "upk_conv_ln_rows": (C.c_int, [vp, C.POINTER(ConvDesc), C.POINTER(C.c_int)]),
             "upk_geglu_mlp_f16": (C.c_int, [vp, C.POINTER(MlpDesc), vp]),
             "upk_geglu_mlp_supported": (C.c_int, [vp, C.POINTER(MlpDesc)]),

@@ -1145,7 +1145,7 @@ extern "C" int upk_conv_override(upk_ctx* ctx, int cfg, int splitk) {
 // launch == false: stops after the (config, split-K) decision and reports whether the reduce pass will
 // produce GroupNorm partials (upk_conv_gn_fused)
 static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, bool launch, int* gn_fused,
-                     int* gn_nblk = nullptr, bool* on_patch = nullptr, int* lnr_slots = nullptr) {
+                     int* gn_nblk = nullptr, int* lnr_slots = nullptr) {
   if (lnr_slots) *lnr_slots = 0;
   if (!ctx || !d) return UPK_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
@@ -1204,7 +1204,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   a.ph_wstride = 0;
   static const bool ph_off = getenv("UPK_NO_PHASES") != nullptr;
   const bool phases = d->w_phase && a.ups && d->ksize == 3 && d->stride == 1 && !(flags & UPK_F_PAD_ASYM) && !ph_off &&
-                      !d->x3 && !d->ln_colsum && !d->vt && !d->residual && !d->rowvec && !d->pc_enable &&
+                      !d->x3 && !d->ln_colsum && !d->vt && !d->residual && !d->rowvec &&
                       !(flags & (UPK_F_GEGLU | UPK_F_OUT_NCHW_F32));
   const int pad = (d->ksize == 3) ? 1 : 0;
   if (phases) {
@@ -1272,16 +1272,6 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   a.flags = flags;
   if (const char* ab = getenv("UPK_ABLATE")) a.flags |= (int)strtol(ab, nullptr, 0) & 0x3F0000;
   a.dbg = (unsigned long long*)((char*)ctx->ws + ctx->ws_bytes - 4096);
-
-  if (d->pc_enable) {  // A-stationary patch kernel (pconv.hip)
-    bool handled = false;
-    const int rc = pconv_run(ctx, d, a, stream, launch, gn_fused, gn_nblk, &handled);
-    if (on_patch) *on_patch = handled;
-    if (rc != UPK_OK || handled) return rc;
-  }
-  if (d->gni_mode)
-    return upk_fail(ctx, UPK_ESHAPE, "conv: GroupNorm folded into the input needs the patch kernel (pc_enable, stride 1, "
-                    "no upsample / transposed-V tail / folded LayerNorm)");
 
   // ---- choose config + split-K ----
   int best = -1, best_sk = 1;
@@ -1481,25 +1471,9 @@ extern "C" int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_str
   return conv_impl(ctx, d, stream, true, nullptr);
 }
 
-extern "C" int upk_pconv_supported(upk_ctx* ctx, const upk_conv_desc* d) {
-  if (!ctx || !d || !d->pc_enable) return 0;
-  upk_conv_desc dd = *d;
-  if (dd.gni_mode) {  // the statistics may not be known yet: only the geometry is probed (tiles inside one sample)
-    static const float dummy = 0.f;
-    dd.gni_mode = 1;
-    dd.gni_gamma = dd.gni_beta = dd.gni_stats1 = &dummy;
-    dd.gni_nblk1 = 1;
-    if (dd.gni_groups <= 0) dd.gni_groups = 32;
-  }
-  bool on_patch = false;
-  const int rc = conv_impl(ctx, &dd, nullptr, false, nullptr, nullptr, &on_patch);
-  ctx->err[0] = 0;
-  return rc == UPK_OK && on_patch ? 1 : 0;
-}
-
 extern "C" int upk_conv_ln_rows(upk_ctx* ctx, const upk_conv_desc* d, int* slots) {
   if (!slots) return UPK_EINVAL;
-  return conv_impl(ctx, d, nullptr, false, nullptr, nullptr, nullptr, slots);
+  return conv_impl(ctx, d, nullptr, false, nullptr, nullptr, slots);
 }
 
 extern "C" int upk_conv_gn_fused(upk_ctx* ctx, const upk_conv_desc* d, int* mode, int* nblk) {

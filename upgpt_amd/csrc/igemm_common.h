@@ -1,4 +1,4 @@
-// Shared by igemm.hip and pconv.hip: launch arguments, LDS swizzle and the epilogues of the implicit-GEMM kernels.
+// Shared by igemm.hip, astat.hip, mlp.hip and xblock.hip: launch arguments, LDS swizzle and the epilogues of the implicit-GEMM kernels.
 #pragma once
 #include <stdlib.h>
 
@@ -63,25 +63,7 @@ struct IgemmArgs {
   int chunks_per_split;
   int tiles_m, tiles_n;
   int flags;
-  // ---- A-stationary patch kernel (pconv.hip): the input patch of an M tile (+ 3x3 halo) is staged ONCE in LDS,
-  // through registers, with the producer GroupNorm(+SiLU) applied on the way
-  int tile_rows;   // valid output rows per M tile (<= BM; tiles never straddle a sample); 0: BM (igemm kernels)
-  int p_pw;        // patch width in pixels (>= Wo + 2*pad; chosen for conflict-free fragment reads)
-  int p_np;        // patch pixels staged per slab
-  int p_ps;        // bytes per patch pixel (= 2*p_cs + 32: 32 mod 64 keeps ds_read_b128 of 16 consecutive pixels conflict free)
-  int p_cs;        // channels per slab (multiple of 32)
-  int p_tpp_log2;  // log2(threads per patch pixel) in the staging pass
-  int p_T;         // total number of ring stages
-  int p_xcd;       // XCD-aware tile order (all M tiles of an N tile on one XCD)
-  int p_tab;       // bytes of the GroupNorm scale / shift table in LDS
-  int gni_mode;    // GroupNorm on the INPUT: 0 none, 1 per-(chunk, group) partials, 2 per-(row block, channel) partials
-  int gni_silu, gni_groups, gni_cpg;
-  float gni_eps;
-  const float* gni_gamma;
-  const float* gni_beta;
-  const float* gni_s1;  // mode 1: [B][nblk1][groups][2]; mode 2: [B][nblk1][2][ld1] of source 1
-  const float* gni_s2;  // mode 2: partials of the second (concat) source
-  int gni_nblk1, gni_ld1, gni_nblk2, gni_ld2;
+  int tile_rows;   // valid output rows per M tile (<= BM); 0: BM
   // ---- LayerNorm row statistics handed from the producer of a tensor to the folded-LayerNorm GEMM that reads it
   float* lnr_out;        // plain epilogue also writes per-(column slot, row) {sum, sum of squares} of what it stores:
                          // [slots][M][2], slot = (output column) / (columns per wave); nullptr: no
@@ -494,7 +476,7 @@ struct Epi {
         if (cp) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const float f = r.ok ? (float)o[k] : 0.f;  // (rows past the tile's valid range: pconv partial tiles)
+            const float f = r.ok ? (float)o[k] : 0.f;  // (rows past the tile's valid range)
             cs[j][k] += f;
             cq[j][k] += f * f;
           }
@@ -618,9 +600,5 @@ const char* astat_config_name(int c);
 int astat_config_ni(int c);
 bool astat_plan(const upk_ctx* ctx, const IgemmArgs& a, int c, int ppw_req, AsPlan* pl);
 int astat_launch(upk_ctx* ctx, IgemmArgs& a, int c, const AsPlan& pl, dim3 grid, hipStream_t stream);
-
-// pconv.hip: runs the launch on the A-stationary patch kernel when the shape is inside its domain
-int pconv_run(upk_ctx* ctx, const upk_conv_desc* d, IgemmArgs& a, hipStream_t stream, bool launch, int* gn_fused,
-              int* gn_nblk, bool* handled);
 
 }  // namespace upkd

@@ -64,14 +64,10 @@ class TuneCache:
 
 
 TUNE_CACHE = TuneCache(os.environ.get("UPGPT_TUNE_FILE") or None)
-# A-stationary patch kernel (csrc/pconv.hip, GroupNorm folded into its staging pass): "0" (default) / "auto" / "all".
-# Off by default: parity-green, but inside the replayed forward it does not beat implicit GEMM + GroupNorm launch yet
-# (profiles/r02_pconv_*): 3.61 ms vs 3.52 ms per forward with the "auto" rule below.
-PCONV_MODE = os.environ.get("UPGPT_PCONV", "0")
 # GroupNorm statistics of the VAE decoder's tensors as conv by-products (gn_stats_cap + upk_groupnorm_finalize_f32):
 # measured neutral (8.29 vs 8.29 ms per decode) — the statistics pass runs at 5.6 TB/s since round 2, the channel
 # partials cost the 200-us convs 2-3 % and a 32-block fold per apply workgroup more than the pass it replaces — off
-VAE_GN_BYPRODUCT = os.environ.get("UPGPT_VAE_GN_BYPRODUCT", "0") == "1" or os.environ.get("UPGPT_PCONV", "0") != "0"
+VAE_GN_BYPRODUCT = os.environ.get("UPGPT_VAE_GN_BYPRODUCT", "0") == "1"
 UPS_PHASES = os.environ.get("UPGPT_UPS_PHASES", "1") == "1"
 LN_ROWS = os.environ.get("UPGPT_LN_ROWS", "1") == "1"
 QPROJ_FUSE = os.environ.get("UPGPT_QPROJ_FUSE", "1") == "1"
@@ -86,7 +82,6 @@ XBLOCK = os.environ.get("UPGPT_XBLOCK", "auto")
 XB_ROWS = int(os.environ.get("UPGPT_XB_ROWS", "0"))  # rows per workgroup (16 / 32; 0 = by M)
 # fused head of a SpatialTransformer (csrc/xblock.hip hblock_kernel: proj_in -> norm1 -> q | k | v, one launch instead of two)
 HBLOCK = os.environ.get("UPGPT_HBLOCK", "auto")
-PCONV_ON = PCONV_MODE != "0"
 LN_LAUNCH_US = 3.0  # what a separate LayerNorm launch costs inside the replayed forward (class ablation: 3.8)
 
 
@@ -314,8 +309,6 @@ class Emitter:
         cache = TUNE_CACHE if cache is None else cache
         hits = tuned = missing = 0
         for d, key in self.convs:
-            if d.pc_enable:
-                continue  # (patch-kernel launches pick their tile configuration themselves)
             ent = cache.get(key)
             if ent is None and not tune_missing and key.endswith("_gs"):
                 ent = cache.get(key[:-3])  # (statistics by-product armed on a shape that was tuned without it)
@@ -367,8 +360,6 @@ class Emitter:
         mode = os.environ.get("UPGPT_SKIP_FOLD", "auto")
         if mode != "auto":
             return mode == "1"
-        if PCONV_MODE == "all" and pw_main.ksize == 3:
-            return True  # the patch kernel takes the appended segment as one more slab of its K loop
         c3, c4 = _rup(x.C, 32), (_rup(skip.C, 32) if skip is not None else 0)
         base = (hN.M, pw_main.n_pad, _rup(hN.C, 32), 0, pw_main.ksize, 1, 0)
         def tuned(key):  # (a launch whose output feeds a GroupNorm is tuned under its "_gs" name)
@@ -401,23 +392,6 @@ class Emitter:
             return False
         return e_f[2] < e_a[2] + e_b[2]
 
-    @staticmethod
-    def pconv_pays(M, ks, concat, appended):
-        """Where the patch kernel (GroupNorm folded into its staging pass) beats implicit GEMM + GroupNorm launch on an
-        MI355X (scripts/pc_bench.py vs scripts/op_trace.py, B = 8): the long-M levels with one staging slab —
-        3x3 224->224 @32x32 22.7 vs 28.5 us, (448+224)->224 48.1 vs 59.3, 448->448 @16x16 27.2 vs 32.8, 1x1 proj_in
-        @32x32 12.2 vs 14.3.  The 8x8 / 4x4 levels (weight streaming: 41 vs 33 us, 32 vs 23) and launches with an
-        appended 1x1 segment (36 vs 33) stay on the split-K implicit GEMM.  UPGPT_PCONV=all forces it everywhere."""
-        if PCONV_MODE == "all":
-            return True
-        if PCONV_MODE == "k1":  # only the GroupNorm -> proj_in pairs (1x1, no SiLU, no halo)
-            return ks == 1
-        if appended:
-            return False
-        if ks == 3:
-            return M >= 8192 or (M >= 2048 and not concat)
-        return True
-
     def ln_linear(self, P, x, name, norm, flags=0, **kw):
         """LayerNorm `norm` followed by the Linear `name`: either one launch with the norm folded into the
         GEMM (weights packed as name + "_ln") or LayerNorm launch + plain GEMM, whichever the tuning
@@ -429,7 +403,7 @@ class Emitter:
         split-K), the fold takes them from there instead: no LayerNorm launch, no statistics work in the GEMM, any
         tile configuration (UPGPT_LN_ROWS=0 switches this off)."""
         prod = getattr(x, "ln_src", None)
-        if LN_ROWS and prod is not None and not prod.ln_rows_out and not prod.pc_enable and x.C == x.ld:
+        if LN_ROWS and prod is not None and not prod.ln_rows_out and x.C == x.ld:
             rows = self.alloc(8, x.M, 2, dtype=torch.float32)
             prod.ln_rows_out = rows.data_ptr()
             out = kw.pop("out", None)
@@ -463,15 +437,15 @@ class Emitter:
         """Emits one upk_conv2d_nhwc_f16. Returns the output Act (fp16) unless nchw_out /
         out_f32 is given.
 
-        gn = (gamma, beta, eps, silu, ws): x1 | x2 are UN-normalised and the GroupNorm(+SiLU) in front of this conv
-        (openaimodel.py:255-275, attention.py:250-256) is folded into the patch kernel's staging pass
-        (include/upk.h gni_*); shapes outside that kernel's domain get the GroupNorm launch + a plain conv."""
+        gn = (gamma, beta, eps, silu, ws[, sole]): x1 | x2 are UN-normalised; the GroupNorm(+SiLU) in front of this conv
+        (openaimodel.py:255-275, attention.py:250-256) is emitted first (Emitter.groupnorm: apply-only when the producer
+        left the statistics, inside the producer's split-K reduce pass when it has one)."""
         B, H, W = spatial if spatial is not None else (x1.B, x1.H, x1.W)
         ks = pw.ksize
         kw_all = dict(stride=stride, flags=flags, residual=residual, rowvec=rowvec, rv_bs=rv_bs, rv_ss=rv_ss, step=step,
                       out=out, vt=vt, nchw_out=nchw_out, out_f32=out_f32, spatial=spatial, ln_eps=ln_eps,
                       gn_stats=gn_stats, append=append, lnr=lnr, lnr_alt=lnr_alt)
-        if gn is not None and not PCONV_ON:
+        if gn is not None:
             return self.conv(P, self.groupnorm(P, x1, *gn[:5], x2=x2, sole=len(gn) > 5 and gn[5]), pw, **kw_all)
         ups = bool(flags & L.F_UPSAMPLE2X)
         HL, WL = (2 * H, 2 * W) if ups else (H, W)
@@ -509,7 +483,6 @@ class Emitter:
         if step is not None:
             d.step = step.data_ptr()
         ret = None
-        out_mine = False
         if nchw_out is not None:
             d.y = nchw_out.data_ptr()
             d.ldy = 0
@@ -519,7 +492,6 @@ class Emitter:
             d.ldy = out_f32.shape[-1]
             flags |= L.F_OUT_F32
         else:
-            out_mine = out is None
             if out is None:
                 ld = pw.n_out if pw.n_out % 32 == 0 else _rup(pw.n_out, 32)  # (a consumer conv reads 32-channel chunks)
                 out = Act(self.alloc(M, ld, zero=(ld != pw.n_out)), B, Ho, Wo, pw.n_out)
@@ -557,17 +529,6 @@ class Emitter:
             require(d.c3 + d.c4 == pw.k_append, lambda: repr(("appended K mismatch", d.c3, d.c4, pw.k_append)), ValueError)
         else:
             require(not pw.k_append, "weight was packed with an appended segment but the launch has none", ValueError)
-        use_pc = (PCONV_ON and stride == 1 and not ups and not (flags & L.F_PAD_ASYM) and ln_eps is None and vt is None
-                  and (ks == 3 or gn is not None) and self.pconv_pays(M, ks, x2 is not None, append is not None))
-        if use_pc:
-            d.pc_enable = 1
-            d.gni_mode, d.gni_groups = (1, 32) if gn is not None else (0, 0)  # (provisional: fixed when the program runs)
-            if not self.lib.upk_pconv_supported(self.hctx, C.byref(d)):
-                d.pc_enable, d.gni_mode, use_pc = 0, 0, False
-        if gn is not None and not use_pc:  # outside the patch kernel's domain: GroupNorm launch + plain conv
-            if out_mine:
-                self.bufs.pop()  # (the output buffer allocated above is re-made by the plain call)
-            return self.conv(P, self.groupnorm(P, x1, *gn[:5], x2=x2, sole=len(gn) > 5 and gn[5]), pw, **kw_all)
         key = self.conv_key(M, pw.n_pad, d.c1, d.c2, ks, stride, flags, residual is not None, rowvec is not None,
                             vt is not None, ln_eps is not None and lnr is None, ka=d.c3 + d.c4)
         if lnr is not None:
@@ -576,8 +537,6 @@ class Emitter:
             # its sk = 1-only autotune result must not pessimise the plain GEMM either (apply_tuning falls back to the
             # plain entry only when that one does not split K)
             key += "_lnr"
-        if use_pc:
-            key += "_pc" + ("" if gn is None else "_gn%d" % int(bool(gn[3])))
         if phased:
             key += "_ph"
         self.convs.append((d, key))
@@ -600,43 +559,8 @@ class Emitter:
                     alt.run(s)
 
             P.add(run_lnr, *keep, lnr, prod, alt, cls="igemm_k%d" % ks, label=key)
-        elif gn is None:
-            P.add(lambda s: chk(fn(h, ref, s)), *keep, cls="igemm_k%d" % ks, label=key)
         else:
-            gamma, beta, eps, silu, ws = gn[:5]
-            require(x1.C == d.c1 and (x2 is None or x2.C == d.c2), "fused GroupNorm needs channel counts that are multiples of 32", ValueError)
-            d.gni_gamma, d.gni_beta, d.gni_eps = gamma.data_ptr(), beta.data_ptr(), float(eps)
-            d.gni_silu, d.gni_groups = int(bool(silu)), 32
-            srcs = [x1] if x2 is None else [x1, x2]
-            armed = self._arm_gn_sources(srcs)
-            hw_in = H * W
-            nch = self.lib.upk_groupnorm_chunks(hw_in)
-            fused_fn, stats_fn = self.lib.upk_conv_gn_fused, self.lib.upk_groupnorm_stats_nhwc_f16
-            sa = (x1.t.data_ptr(), x1.C, x1.ld, x2.t.data_ptr() if x2 is not None else None,
-                  x2.C if x2 is not None else 0, x2.ld if x2 is not None else 0, B, hw_in, 32)
-
-            def run(s):
-                info = []
-                for dsrc, sws in (armed or ()):
-                    if isinstance(dsrc, Emitter.GnProvider):
-                        info.append((2, dsrc.nblk, dsrc.ld, sws.data_ptr()))
-                        continue
-                    mode, nblk = C.c_int(0), C.c_int(0)
-                    chk(fused_fn(h, C.byref(dsrc), C.byref(mode), C.byref(nblk)))
-                    info.append((mode.value, nblk.value, dsrc.n_pad, sws.data_ptr()))
-                if info and all(i[0] == 2 and i[1] <= 32 for i in info):
-                    d.gni_mode = 2
-                    d.gni_stats1, d.gni_nblk1, d.gni_ld1 = info[0][3], info[0][1], info[0][2]
-                    if len(info) == 2:
-                        d.gni_stats2, d.gni_nblk2, d.gni_ld2 = info[1][3], info[1][1], info[1][2]
-                elif len(info) == 1 and info[0][0] == 1:
-                    d.gni_mode, d.gni_stats1, d.gni_nblk1 = 1, info[0][3], nch
-                else:  # no usable by-product: statistics pass of the input, then the fused conv
-                    chk(stats_fn(h, *sa, ws.data_ptr(), s))
-                    d.gni_mode, d.gni_stats1, d.gni_nblk1 = 1, ws.data_ptr(), nch
-                chk(fn(h, ref, s))
-
-            P.add(run, *keep, gamma, beta, ws, armed, cls="igemm_k%d" % ks, label=key)
+            P.add(lambda s: chk(fn(h, ref, s)), *keep, cls="igemm_k%d" % ks, label=key)
         P.igemm_flops += 2 * M * pw.n_real * pw.k_real
         P.flops[-1] = 2 * M * pw.n_real * pw.k_real
         return ret
@@ -658,7 +582,7 @@ class Emitter:
             if os.environ.get("UPGPT_GN_2SRC", "1") != "1":
                 return None
             for sr in srcs:
-                if isinstance(sr, Emitter.GnProvider) or sr[0].pc_enable:
+                if isinstance(sr, Emitter.GnProvider):
                     continue  # (never split K)
                 key = self.convs[sr[1]][1]
                 e = TUNE_CACHE.get(key) or TUNE_CACHE.get(key[:-3] if key.endswith("_gs") else key + "_gs")
@@ -849,9 +773,13 @@ class Emitter:
         out = Act(self.alloc(M, C_), t0.B, t0.H, t0.W, C_)
         d.y, d.ldy = out.t.data_ptr(), out.ld
         fn, h, chk = self.lib.upk_cross_block_f16, self.hctx, self._chk
-        P.add(lambda s: chk(fn(h, C.byref(d), s)), d, a1, t0, o1, o2, ql, vec, kc, vtc, out, cls="attention",
+        # (timed with the conv / GEMM class: three of its four stages are GEMMs; its attention FLOPs are counted there too)
+        P.add(lambda s: chk(fn(h, C.byref(d), s)), d, a1, t0, o1, o2, ql, vec, kc, vtc, out, cls="igemm_k1",
               label="xblock M%d C%d d%d rows%d" % (M, C_, dp, rows))
-        P.igemm_flops += 2 * M * (o1.k_real * o1.n_real + ql.k_real * ql.n_real + o2.k_real * o2.n_real)
+        fl = 2 * M * (o1.k_real * o1.n_real + ql.k_real * ql.n_real + o2.k_real * o2.n_real)
+        fl += 4 * M * heads * self.n_ctx * (ql.n_real // heads)
+        P.igemm_flops += fl
+        P.flops[-1] = fl
         return out
 
     def attention(self, P, q, ldq, qbs, k, ldk, kbs, vt, vt_ld, out, ldo, obs, B, heads, nq, nkv, dp, scale):
@@ -1052,7 +980,7 @@ class UNetPlan(Emitter):
         vt_ld = _rup(HW, 32)
         vt = self.alloc(B, heads, dp, vt_ld, zero=True)
         t0 = None
-        if not PCONV_ON and self.head_block_ok(x, t, heads, dp, qk, vt_ld):
+        if self.head_block_ok(x, t, heads, dp, qk, vt_ld):
             xn = self.groupnorm(P, x, *v[n + ".norm"], 1e-6, False, self.gn_ws)
             t0 = self.head_block(P, xn, n, t, heads, dp, qk, vt, vt_ld)
         if t0 is None:
@@ -1067,7 +995,6 @@ class UNetPlan(Emitter):
         kc, vtc, cld = self.kv[n]
         t2 = self.cross_block(P, a1, t0, t, kc, vtc, cld, heads, dp, scale)
         if t2 is not None:
-            P.attn_flops += 4 * B * heads * HW * self.n_ctx * dh
             return self._st_ff(P, Lr, x, t2)
         t1 = self.conv(P, a1, w[t + ".attn1.to_out"], residual=t0)
         a2 = Act(self.alloc(M, hd), B, x.H, x.W, hd)
