@@ -306,6 +306,15 @@ typedef struct upk_hblock_desc {
   void* vt;
   int32_t vt_ld;
   int32_t hw, rows_per_wg;
+  /* gn_part != NULL: x is the UN-normalised input of SpatialTransformer.norm (attention.py:330, GroupNorm without
+   * SiLU) and the normalisation is applied to the tile inside the kernel, bit-identical to a upk_groupnorm_apply launch:
+   * gn_part = the per-(row block, channel) partial sums [m / hw][gn_nblk][2][gn_ld] the producer of x left (gn_stats_ws
+   * mode 2, gn_nblk <= 32), gn_gamma / gn_beta [c], gn_groups groups. */
+  const float* gn_part;
+  const float* gn_gamma;
+  const float* gn_beta;
+  int32_t gn_nblk, gn_ld, gn_groups;
+  float gn_eps;
 } upk_hblock_desc;
 int upk_head_block_f16(upk_ctx* ctx, const upk_hblock_desc* d, upk_stream stream);
 int upk_head_block_supported(upk_ctx* ctx, const upk_hblock_desc* d);

@@ -178,6 +178,51 @@ def test_head_block_vs_torch(ctx, B, hw, rows):
     assert float(vt[..., hw:].abs().max()) == 0.0 if vt_ld > hw else True
 
 
+@pytest.mark.parametrize("B,hw,rows,nblk", [(8, 1024, 32, 16), (2, 64, 16, 4)])
+def test_head_block_groupnorm_fold_is_bit_identical_to_the_launch(ctx, B, hw, rows, nblk):
+    """gn_part: the GroupNorm of the input applied on the tile inside the kernel == upk_groupnorm_apply + plain call."""
+    heads, c, dp = 8, 224, 32
+    M, hd = B * hw, heads * dp
+    x = (rnd(M, c, seed=1) * 1.7 + 0.4).half()
+    gamma, beta = 1 + 0.3 * rnd(c, seed=2), 0.2 * rnd(c, seed=3)
+    w1p, _ = ctx.pack_weight(rnd(c, c, scale=1 / math.sqrt(c), seed=4).contiguous())
+    w2p, _ = ctx.pack_weight(rnd(3 * hd, c, scale=1 / math.sqrt(c), seed=5).contiguous())
+    vec = torch.cat([rnd(c, scale=0.1, seed=6), rnd(3 * hd, scale=0.3, seed=7), rnd(3 * hd, scale=0.1, seed=8)])
+    vec = torch.cat([vec, vec.new_zeros(-vec.numel() % 256)]).contiguous()
+    # per-(row block, channel) partials as a producer's epilogue leaves them: [B][nblk][2][ld]
+    ld = c
+    xf = x.float().reshape(B, nblk, hw // nblk, c)
+    part = torch.stack([xf.sum(2), (xf * xf).sum(2)], dim=2).contiguous()
+    vt_ld = (hw + 31) // 32 * 32
+    outs = []
+    for fold in (False, True):
+        t0 = torch.zeros(M, c, device=DEV, dtype=torch.float16)
+        qk = torch.zeros(M, 2 * hd, device=DEV, dtype=torch.float16)
+        vt = torch.zeros(B, heads, dp, vt_ld, device=DEV, dtype=torch.float16)
+        d = L.HblockDesc()
+        d.m, d.c, d.heads, d.d = M, c, heads, dp
+        d.w_in, d.w_qkv, d.vec, d.ln_eps, d.ln_dim = w1p.data_ptr(), w2p.data_ptr(), vec.data_ptr(), 1e-5, c
+        d.t0, d.ld_t0, d.qk, d.ld_qk, d.vt, d.vt_ld = t0.data_ptr(), c, qk.data_ptr(), 2 * hd, vt.data_ptr(), vt_ld
+        d.hw, d.rows_per_wg = hw, rows
+        if fold:
+            d.x, d.ldx = x.data_ptr(), c
+            d.gn_part, d.gn_gamma, d.gn_beta = part.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+            d.gn_nblk, d.gn_ld, d.gn_groups, d.gn_eps = nblk, ld, 32, 1e-6
+        else:
+            xn = torch.zeros_like(x)
+            ctx._chk(ctx.lib.upk_groupnorm_apply_nhwc_f16(ctx.h, x.data_ptr(), c, c, None, 0, 0, B, hw, 32, gamma.data_ptr(),
+                                                          beta.data_ptr(), 1e-6, 0, xn.data_ptr(), c, part.data_ptr(), 2, nblk,
+                                                          ld, None, 0, 0, ctx._s()))
+            d.x, d.ldx = xn.data_ptr(), c
+        ctx._chk(ctx.lib.upk_head_block_f16(ctx.h, C.byref(d), ctx._s()))
+        torch.cuda.synchronize()
+        outs.append((t0, qk, vt))
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+    ref = F.group_norm(x.float().reshape(B, hw, c).permute(0, 2, 1), 32, gamma, beta, 1e-6).permute(0, 2, 1).reshape(M, c)
+    assert float(ref.abs().max()) > 1.0  # (sanity of the test data)
+
+
 def test_unet_forward_with_and_without_the_fused_head():
     import upgpt_amd
     from upgpt_amd import engine, synth

@@ -100,6 +100,8 @@ class HblockDesc(C.Structure):
         ("w_in", C.c_void_p), ("w_qkv", C.c_void_p), ("vec", C.c_void_p), ("ln_eps", C.c_float), ("ln_dim", C.c_int32),
         ("t0", C.c_void_p), ("ld_t0", C.c_int32), ("qk", C.c_void_p), ("ld_qk", C.c_int32),
         ("vt", C.c_void_p), ("vt_ld", C.c_int32), ("hw", C.c_int32), ("rows_per_wg", C.c_int32),
+        ("gn_part", C.c_void_p), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p),
+        ("gn_nblk", C.c_int32), ("gn_ld", C.c_int32), ("gn_groups", C.c_int32), ("gn_eps", C.c_float),
     ]
 
 

@@ -422,10 +422,17 @@ struct HbArgs {
   f16* vt;           // [B, heads, d, vt_ld]
   int ldx, ldt0, ldqk, vt_ld, M, hw, vec_pieces;
   float ln_inv_dim, ln_eps;
+  // GroupNorm of the input folded in (GNF): x is un-normalised, the statistics come from the per-(row block, channel)
+  // partials its producer's epilogue left ([B][gn_nblk][2][gn_ld], include/upk.h gn_stats_ws mode 2)
+  const float* gn_part;
+  const float* gn_gamma;
+  const float* gn_beta;
+  int gn_nblk, gn_ld, gn_cpg;
+  float gn_eps;
   unsigned long long* dbg;
 };
 
-template <int MI, int C32, int DP>
+template <int MI, int C32, int DP, bool GNF>
 __global__ __launch_bounds__(512) void hblock_kernel(const HbArgs s) {
   constexpr int NW = XB_NW, BM = MI * 16;
   constexpr int C = C32 * 32, HD = NW * DP, N2 = 3 * HD;
@@ -437,6 +444,7 @@ __global__ __launch_bounds__(512) void hblock_kernel(const HbArgs s) {
   extern __shared__ __attribute__((aligned(16))) f16 smem[];
   XB_PIN(s.x); XB_PIN(s.w1); XB_PIN(s.w2); XB_PIN(s.zero); XB_PIN(s.vec); XB_PIN(s.t0); XB_PIN(s.qk); XB_PIN(s.vt);
   XB_PIN(s.ldx); XB_PIN(s.ldt0); XB_PIN(s.ldqk); XB_PIN(s.vt_ld); XB_PIN(s.M); XB_PIN(s.hw); XB_PIN(s.vec_pieces);
+  if (GNF) { XB_PIN(s.gn_part); XB_PIN(s.gn_gamma); XB_PIN(s.gn_beta); XB_PIN(s.gn_nblk); XB_PIN(s.gn_ld); XB_PIN(s.gn_cpg); }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -453,13 +461,16 @@ __global__ __launch_bounds__(512) void hblock_kernel(const HbArgs s) {
   const int m0 = blockIdx.x * BM;
   const int b = m0 / s.hw;
   const int tok0 = m0 - b * s.hw;
-  f16* const aT = smem;                            // [C32][BM][32]  xn
+  f16* const aT = smem;                            // [C32][BM][32]  xn (x until the GroupNorm is applied in place)
   f16* const tT = smem + C32 * BM * 32;            // [C32][BM][32]  t0
   float* const st = (float*)(tT + C32 * BM * 32);  // [BM][2]
   float* const bl = st + BM * 2;
   const float* const bl_b1 = bl;
   const float* const bl_u2 = bl + C;
   const float* const bl_b2 = bl + C + N2;
+  float* const tab = bl + s.vec_pieces * 256;      // GNF: [2][C] channel sums, then scale | shift
+  double* const gsum = (double*)(tab + 2 * C);     // GNF: [groups][2]
+  float* const gst = (float*)(gsum + 2 * UPK_GN_GROUPS_MAX);  // GNF: mean[groups], rstd[groups]
   {
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
@@ -474,6 +485,18 @@ __global__ __launch_bounds__(512) void hblock_kernel(const HbArgs s) {
     }
     for (int idx = wave; idx < s.vec_pieces; idx += NW)
       __builtin_amdgcn_global_load_lds((glb_ptr)(s.vec + idx * 256 + lane * 4), (lds_ptr)(bl + idx * 256), 16, 0, 0);
+  }
+  // GNF: this thread's (sum | sum of squares, channel) column of the producer's partials, blocks added in index order
+  // (norm.hip gn_apply_kernel's arithmetic: fp32 over the blocks, fp64 over a group's channels), and its gamma / beta
+  float gn_acc = 0.f, gn_g = 0.f, gn_b = 0.f;
+  if (GNF) {
+    if (tid < 2 * C) {
+      const int which = tid >= C ? 1 : 0;
+      const float* src = s.gn_part + (long)b * s.gn_nblk * 2 * s.gn_ld + which * s.gn_ld + (tid - which * C);
+#pragma unroll 8
+      for (int k = 0; k < s.gn_nblk; ++k) gn_acc += src[(long)k * 2 * s.gn_ld];
+    }
+    if (tid < C) gn_g = s.gn_gamma[tid], gn_b = s.gn_beta[tid];
   }
   const bool act1 = wave < 7;
   const int colw = (act1 ? wave : 6) * NI1 * 16;  // (wave 7: wave 6's columns, results dropped — one instruction stream)
@@ -494,6 +517,49 @@ __global__ __launch_bounds__(512) void hblock_kernel(const HbArgs s) {
   f16x8 ring2[PF][NIQ];
   xb_fill<NIQ, PF>(ring2, wb2, ks2, loff);
   __builtin_amdgcn_sched_barrier(0);
+  if (GNF) {
+    if (tid < 2 * C) tab[tid] = gn_acc;
+    xb_lds_barrier();
+    const int groups = C / s.gn_cpg;
+    if (tid < groups * 2) {
+      const int g = tid >> 1, which = tid & 1;
+      double acc = 0.0;
+      for (int e = 0; e < s.gn_cpg; ++e) acc += (double)tab[which * C + g * s.gn_cpg + e];
+      gsum[tid] = acc;
+    }
+    xb_lds_barrier();
+    if (tid < groups) {
+      const double n = (double)s.hw * s.gn_cpg;
+      const double mean = gsum[tid * 2] / n;
+      double var = gsum[tid * 2 + 1] / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      gst[tid] = (float)mean;
+      gst[UPK_GN_GROUPS_MAX + tid] = (float)(1.0 / sqrt(var + (double)s.gn_eps));
+    }
+    xb_lds_barrier();
+    if (tid < C) {
+      const int g = tid / s.gn_cpg;
+      const float sc = gst[UPK_GN_GROUPS_MAX + g] * gn_g;
+      tab[tid] = sc;
+      tab[C + tid] = gn_b - gst[g] * sc;
+    }
+    xb_lds_barrier();
+    // the tile in place: y = fp16(x * scale + shift), the value the GroupNorm launch would have stored
+    for (int v = tid; v < C32 * BM * 4; v += 512) {
+      const int kc = v / (BM * 4), rem = v - kc * (BM * 4);
+      const int row = rem >> 2, slot = rem & 3;
+      const int ch = kc * 32 + (slot ^ ((-((row & 15) >> 2)) & 3)) * 8;  // (the piece that the swizzle put in this slot)
+      f16x8* p = (f16x8*)(aT + (kc * BM + row) * 32 + slot * 8);
+      const f16x8 xv = *p;
+      const f32x4 sc0 = *(const f32x4*)(tab + ch), sc1 = *(const f32x4*)(tab + ch + 4);
+      const f32x4 sh0 = *(const f32x4*)(tab + C + ch), sh1 = *(const f32x4*)(tab + C + ch + 4);
+      f16x8 yv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) yv[j] = (f16)((float)xv[j] * (j < 4 ? sc0[j] : sc1[j - 4]) + (j < 4 ? sh0[j] : sh1[j - 4]));
+      *p = yv;
+    }
+    xb_lds_barrier();
+  }
 
   const unsigned la = (unsigned)(lc * 32 + lds_swz(lc, lg) * 8) * 2u;
   auto tile_at = [&](f16* T, int row, int n) -> f16* {
@@ -699,8 +765,19 @@ extern "C" int upk_head_block_f16(upk_ctx* ctx, const upk_hblock_desc* d, upk_st
   s.dbg = getenv("UPK_XB_TL") ? (unsigned long long*)((char*)ctx->ws + ctx->ws_bytes - 4096) : nullptr;
 #endif
   const int bm = d->rows_per_wg > 0 ? d->rows_per_wg : 32;
-  void (*fn)(const HbArgs) = bm == 32 ? hblock_kernel<2, 7, 32> : hblock_kernel<1, 7, 32>;
-  const size_t lds = (size_t)2 * (d->c / 32) * bm * 64 + (size_t)bm * 8 + (size_t)s.vec_pieces * 1024;
+  const bool gnf = d->gn_part != nullptr;
+  if (gnf) {
+    if (!d->gn_gamma || !d->gn_beta || d->gn_groups <= 0 || d->c % d->gn_groups || d->gn_groups > UPK_GN_GROUPS_MAX ||
+        d->gn_nblk <= 0 || d->gn_nblk > UPK_GN_MAX_CHUNKS || d->gn_ld < d->c)
+      return upk_fail(ctx, UPK_EINVAL, "head_block: bad GroupNorm operands (groups=%d nblk=%d ld=%d)", d->gn_groups,
+                      d->gn_nblk, d->gn_ld);
+    s.gn_part = d->gn_part, s.gn_gamma = d->gn_gamma, s.gn_beta = d->gn_beta;
+    s.gn_nblk = d->gn_nblk, s.gn_ld = d->gn_ld, s.gn_cpg = d->c / d->gn_groups, s.gn_eps = d->gn_eps;
+  }
+  void (*fn)(const HbArgs) = bm == 32 ? (gnf ? hblock_kernel<2, 7, 32, true> : hblock_kernel<2, 7, 32, false>)
+                                      : (gnf ? hblock_kernel<1, 7, 32, true> : hblock_kernel<1, 7, 32, false>);
+  const size_t lds = (size_t)2 * (d->c / 32) * bm * 64 + (size_t)bm * 8 + (size_t)s.vec_pieces * 1024 +
+                     (gnf ? (size_t)2 * d->c * 4 + 2 * UPK_GN_GROUPS_MAX * 8 + 2 * UPK_GN_GROUPS_MAX * 4 : 0);
   upk_prof_scope prof(ctx, UPK_CLS_IGEMM, stream);
   hipLaunchKernelGGL(fn, dim3(d->m / bm), dim3(512), lds, stream, s);
   return upk_check_launch(ctx, "head_block");

@@ -82,6 +82,7 @@ XBLOCK = os.environ.get("UPGPT_XBLOCK", "auto")
 XB_ROWS = int(os.environ.get("UPGPT_XB_ROWS", "0"))  # rows per workgroup (16 / 32; 0 = by M)
 # fused head of a SpatialTransformer (csrc/xblock.hip hblock_kernel: proj_in -> norm1 -> q | k | v, one launch instead of two)
 HBLOCK = os.environ.get("UPGPT_HBLOCK", "auto")
+HBLOCK_GN = os.environ.get("UPGPT_HBLOCK_GN", "1") == "1"  # SpatialTransformer.norm applied on the tile inside that launch
 LN_LAUNCH_US = 3.0  # what a separate LayerNorm launch costs inside the replayed forward (class ablation: 3.8)
 
 
@@ -721,15 +722,23 @@ class Emitter:
             return False
         return HBLOCK == "1" or x.M // rows >= self.ctx.num_cus
 
-    def head_block(self, P, xn, n, t, heads, dp, qk, vt, vt_ld):
-        """proj_in -> norm1 -> q | k | v as ONE launch (include/upk.h upk_head_block_f16) on the GroupNorm output xn;
-        returns t0.  Call head_block_ok first."""
+    def head_block(self, P, x, n, t, heads, dp, qk, vt, vt_ld, gn):
+        """SpatialTransformer.norm -> proj_in -> norm1 -> q | k | v (include/upk.h upk_head_block_f16); returns t0.
+        gn = (gamma, beta, eps, ws): the GroupNorm of x.  When the producer of x left per-(row block, channel) partial
+        statistics (decided when the program runs, as in Emitter.groupnorm) the normalisation happens on the tile inside
+        the kernel: ONE launch; otherwise a GroupNorm launch writes xn first.  Call head_block_ok first."""
         w = self.pk.w
         vec = w[t + ".hblock.vec"]
-        M, C_ = xn.M, xn.C
-        hw = xn.H * xn.W
+        gamma, beta, eps, ws = gn
+        M, C_ = x.M, x.C
+        hw = x.H * x.W
         rows = XB_ROWS or 32
         pi, qkv = w[n + ".proj_in"], w[t + ".attn1.qkv_ln"]
+        armed = self._arm_gn_sources([x]) if HBLOCK_GN else None
+        if armed is None:
+            xn = self.groupnorm(P, x, gamma, beta, eps, False, ws)
+        else:
+            xn = Act(self.alloc(M, C_), x.B, x.H, x.W, C_)  # (written only when the statistics are not of the usable kind)
         d = L.HblockDesc()
         d.x, d.ldx, d.m, d.c, d.heads, d.d = xn.t.data_ptr(), xn.ld, M, C_, heads, dp
         d.w_in, d.w_qkv, d.vec = pi.w.data_ptr(), qkv.w.data_ptr(), vec.data_ptr()
@@ -737,11 +746,43 @@ class Emitter:
         d.qk, d.ld_qk, d.vt, d.vt_ld = qk.t.data_ptr(), qk.ld, vt.data_ptr(), vt_ld
         d.hw, d.rows_per_wg = hw, rows
         require(self.lib.upk_head_block_supported(self.hctx, C.byref(d)), "head_block: unsupported shape", RuntimeError)
-        t0 = Act(self.alloc(M, C_), xn.B, xn.H, xn.W, C_)
+        t0 = Act(self.alloc(M, C_), x.B, x.H, x.W, C_)
         d.t0, d.ld_t0 = t0.t.data_ptr(), t0.ld
         fn, h, chk = self.lib.upk_head_block_f16, self.hctx, self._chk
-        P.add(lambda s: chk(fn(h, C.byref(d), s)), d, xn, pi, qkv, vec, t0, qk, vt, cls="igemm_k1",
-              label="hblock M%d C%d d%d rows%d" % (M, C_, dp, rows))
+        label = "hblock M%d C%d d%d rows%d" % (M, C_, dp, rows)
+        if armed is None:
+            P.add(lambda s: chk(fn(h, C.byref(d), s)), d, xn, pi, qkv, vec, t0, qk, vt, cls="igemm_k1", label=label)
+        else:
+            fused_fn, apply_fn = self.lib.upk_conv_gn_fused, self.lib.upk_groupnorm_apply_nhwc_f16
+            fin_fn, gn_fn = self.lib.upk_groupnorm_finalize_f32, self.lib.upk_groupnorm_nhwc_f16
+            a = (x.t.data_ptr(), x.C, x.ld, None, 0, 0, x.B, hw, 32, gamma.data_ptr(), beta.data_ptr(), float(eps), 0,
+                 xn.t.data_ptr(), xn.ld)
+            src, sws = armed[0]
+
+            def run(s):
+                if isinstance(src, Emitter.GnProvider):
+                    mode, nb, ld = 2, src.nblk, src.ld
+                else:
+                    m_, n_ = C.c_int(0), C.c_int(0)
+                    chk(fused_fn(h, C.byref(src), C.byref(m_), C.byref(n_)))
+                    mode, nb, ld = (m_.value if m_.value != 3 else 0), n_.value, src.n_pad
+                if mode == 2 and nb <= 32:
+                    d.x, d.ldx = x.t.data_ptr(), x.ld
+                    d.gn_part, d.gn_gamma, d.gn_beta = sws.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+                    d.gn_nblk, d.gn_ld, d.gn_groups, d.gn_eps = nb, ld, 32, float(eps)
+                    chk(fn(h, C.byref(d), s))
+                    return
+                if mode == 2:
+                    chk(fin_fn(h, sws.data_ptr(), nb, ld, x.B, hw, x.C, 32, ws.data_ptr(), s))
+                    chk(apply_fn(h, *a, ws.data_ptr(), 1, 0, 0, None, 0, 0, s))
+                elif mode:
+                    chk(apply_fn(h, *a, sws.data_ptr(), mode, nb, ld, None, 0, 0, s))
+                else:
+                    chk(gn_fn(h, *a, ws.data_ptr(), s))
+                d.x, d.ldx, d.gn_part = xn.t.data_ptr(), xn.ld, None
+                chk(fn(h, C.byref(d), s))
+
+            P.add(run, d, x, xn, gamma, beta, ws, armed, pi, qkv, vec, t0, qk, vt, cls="igemm_k1", label=label + " gn")
         fl = 2 * M * (pi.k_real * pi.n_real + qkv.k_real * qkv.n_real)
         P.igemm_flops += fl
         P.flops[-1] = fl
@@ -981,8 +1022,7 @@ class UNetPlan(Emitter):
         vt = self.alloc(B, heads, dp, vt_ld, zero=True)
         t0 = None
         if self.head_block_ok(x, t, heads, dp, qk, vt_ld):
-            xn = self.groupnorm(P, x, *v[n + ".norm"], 1e-6, False, self.gn_ws)
-            t0 = self.head_block(P, xn, n, t, heads, dp, qk, vt, vt_ld)
+            t0 = self.head_block(P, x, n, t, heads, dp, qk, vt, vt_ld, (*v[n + ".norm"], 1e-6, self.gn_ws))
         if t0 is None:
             t0 = self.conv(P, x, w[n + ".proj_in"], gn=(*v[n + ".norm"], 1e-6, False, self.gn_ws))
             self.ln_linear(P, t0, t + ".attn1.qkv", t + ".norm1", out=qk,  # norm1 -> q|k|v (attention.py:203,212)
