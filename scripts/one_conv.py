@@ -8,6 +8,8 @@ reps = int(sys.argv[9]) if len(sys.argv) > 9 else 20
 ctx = L.get_context(0)
 x = torch.randn(B * H * W, cin, device="cuda").half()
 w = (torch.randn(cout, cin, ks, ks, device="cuda") / math.sqrt(cin * ks * ks)).contiguous()
+if os.environ.get("ZERO") == "1":  # all-zero operands: the MFMA rate without the data-dependent switching power
+    x.zero_(); w.zero_()
 wp, n_pad = ctx.pack_weight(w)
 y = torch.empty(B * H * W, cout, device="cuda", dtype=torch.float16)
 d = L.ConvDesc()

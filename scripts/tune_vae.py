@@ -1,0 +1,51 @@
+"""Re-tunes the conv launches of the VAE decoder (and optionally encoder) on the GPU over every configuration, incl. the
+big-tile family, with realistic activations in the plan's buffers (a decode of random latents runs first: the MFMA rate
+depends on the operand data, all-zero buffers flatter some configurations), and writes the merged tuning cache.
+
+    python scripts/tune_vae.py [out.json] [min_M]
+"""
+import contextlib, io, os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import upgpt_amd
+from upgpt_amd import synth
+from upgpt_amd.engine import TUNE_CACHE
+
+out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/tuned_gfx950.json"
+min_m = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+with contextlib.redirect_stdout(io.StringIO()):
+    model = upgpt_amd.build_model("bbox")
+synth.fill_module_(model); model = model.cuda()
+fs = model.first_stage_model
+
+
+def decode_ms(vp, z, n=10):
+    for _ in range(3): vp.run(z)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): vp.run(z)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+for (B, h, w) in [(8, 32, 32), (8, 32, 24)]:
+    z = torch.randn(B, 4, h, w)
+    vp = fs._decode_plan(B, h, w, 0.18215)
+    before = decode_ms(vp, z)
+    ctx = vp.ctx
+    changed = 0
+    for d, key in vp.convs:
+        M = int(key.split("_")[0][1:])
+        if M < min_m:
+            continue
+        old = TUNE_CACHE.get(key)
+        cfg, sk, best_us, dflt_us = ctx.conv_autotune(d, 4)
+        name = ctx.lib.upk_conv_config_name(cfg).decode()
+        if old is None or (int(old[0]), int(old[1])) != (cfg, sk):
+            changed += 1
+        print("%-52s %s sk %d  %.1f us (was %s)" % (key, name, sk, best_us, old), flush=True)
+        TUNE_CACHE.put(key, cfg, sk, best_us, dflt_us)
+    TUNE_CACHE.save(out)
+    fs._plans.clear()
+    vp = fs._decode_plan(B, h, w, 0.18215)
+    after = decode_ms(vp, z)
+    print("vae decode B=%d %dx%d: %.3f -> %.3f ms (%d launches re-pinned)" % (B, h, w, before, after, changed), flush=True)
+print("entries:", len(TUNE_CACHE.d), "->", out)

@@ -1130,8 +1130,10 @@ double estimate(const CfgInfo& c, int M, int npad, int nchunks, int splitk, int 
 
 // configurations kNumCfgs .. kNumCfgs + astat_num_configs() - 1 are the A-stationary family (astat.hip); for those the
 // "split-K" slot of the tuning pair means output-column passes per workgroup (0 = fill the chip once)
-extern "C" int upk_conv_num_configs(void) { return kNumCfgs + astat_num_configs(); }
+// ... and behind those the big-tile family (bigtile.hip); its second slot is a split-K factor like the first families'
+extern "C" int upk_conv_num_configs(void) { return kNumCfgs + astat_num_configs() + bt_num_configs(); }
 extern "C" const char* upk_conv_config_name(int cfg) {
+  if (cfg >= kNumCfgs + astat_num_configs()) return bt_config_name(cfg - kNumCfgs - astat_num_configs());
   if (cfg >= kNumCfgs) return astat_config_name(cfg - kNumCfgs);
   return (cfg >= 0 && cfg < kNumCfgs) ? kCfgs[cfg].name : "?";
 }
@@ -1282,7 +1284,20 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   const int want_cfg = ctx->cfg_override >= 0 ? ctx->cfg_override : (d->tune_cfg > 0 ? d->tune_cfg - 1 : -1);
   const int want_sk = ctx->splitk_override > 0 ? ctx->splitk_override : (d->tune_splitk > 0 ? d->tune_splitk : 0);
   AsPlan aspl;
-  const bool is_as = want_cfg >= kNumCfgs;
+  const int bt0 = kNumCfgs + astat_num_configs();
+  const bool bt_able = !a.x3 && !(a.ln_u && !a.lnr_in);  // (no appended segment, no fragment-side LayerNorm fold)
+  bool is_bt = want_cfg >= bt0;
+  int bt_bm = 0, bt_bn = 0, bt_occ = 1, bt_mi = 0, bt_ni = 0;
+  if (is_bt) {
+    bt_tile(want_cfg - bt0, &bt_bm, &bt_bn, &bt_occ, &bt_mi, &bt_ni);
+    const int sk = want_sk > 0 ? want_sk : 1;
+    if (!bt_able || (sk == 1 && !Epi::plain(a)) || (a.ln_u && sk > 1) || (sk > 1 && (slab * sk > ctx->ws_bytes || a.nchunks / sk < 4)))
+      return upk_fail(ctx, UPK_ESHAPE, "conv: big-tile configuration %s (split-K %d) does not fit this launch",
+                      bt_config_name(want_cfg - bt0), sk);
+    best = want_cfg;
+    best_sk = sk;
+  }
+  const bool is_as = want_cfg >= kNumCfgs && !is_bt;
   if (is_as) {
     if (!astat_plan(ctx, a, want_cfg - kNumCfgs, want_sk, &aspl) || (want_sk > 1 && want_sk > aspl.npass))
       return upk_fail(ctx, UPK_ESHAPE, "conv: A-stationary configuration %s (passes per workgroup %d) does not fit this launch",
@@ -1290,7 +1305,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     best = want_cfg;
     best_sk = 1;
   }
-  for (int c = 0; c < kNumCfgs && !is_as; ++c) {
+  for (int c = 0; c < kNumCfgs && !is_as && !is_bt; ++c) {
     if (want_cfg >= 0 && c != want_cfg) continue;
     // folded LayerNorm: row statistics come from the M x N-split wave-specialised kernels, whole K in one block
     if (a.ln_u && !a.lnr_in && !kCfgs[c].fn_ln) continue;
@@ -1307,14 +1322,35 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
       }
     }
   }
+  if (want_cfg < 0 && want_sk <= 1 && bt_able && Epi::plain(a) && best >= 0 && best_sk == 1) {
+    // cost model for the big-tile family: MFMA-bound stages (16 cycles per fragment MFMA, four SIMDs in parallel, the
+    // workgroups of a CU taking turns) + prologue / epilogue per tile; only where every CU gets a tile
+    for (int c = 0; c < bt_num_configs(); ++c) {
+      int bm, bn, occ, mi, ni;
+      bt_tile(c, &bm, &bn, &occ, &mi, &ni);
+      if (geglu && ((ni * 16) % 64 != 0)) continue;
+      const long tiles = (long)cdiv(a.M, bm) * cdiv(a.npad, bn) * nph;
+      if (tiles < ctx->num_cus) continue;
+      const double rounds = ceil((double)tiles / ((double)ctx->num_cus * occ));
+      const double t = rounds * occ * ((double)a.nchunks * (mi * ni * 16.0 * 1.2 + 60.0) + 9000.0);
+      if (t < best_t) {
+        best_t = t;
+        best = bt0 + c;
+        best_sk = 1;
+        is_bt = true;
+        bt_bm = bm, bt_bn = bn, bt_occ = occ, bt_mi = mi, bt_ni = ni;
+      }
+    }
+  }
   if (best < 0) {
     if (want_sk > 1 && slab * want_sk > ctx->ws_bytes)
       return upk_fail(ctx, UPK_EWORKSPACE, "conv: split-K %d needs %zu workspace bytes, have %zu", want_sk,
                       slab * want_sk, ctx->ws_bytes);
     return upk_fail(ctx, UPK_ESHAPE, "conv: no kernel configuration fits (geglu=%d)", (int)geglu);
   }
-  const CfgInfo& c = kCfgs[is_as ? 0 : best];  // (not used by the A-stationary family beyond this block)
-  const int BM = is_as ? aspl.bm : c.mi * 16 * c.wm, BN = is_as ? aspl.pw * aspl.ppw : c.ni * 16 * c.wn;
+  const CfgInfo& c = kCfgs[(is_as || is_bt) ? 0 : best];  // (not used by the A-stationary / big-tile families beyond this block)
+  const int BM = is_bt ? bt_bm : (is_as ? aspl.bm : c.mi * 16 * c.wm);
+  const int BN = is_bt ? bt_bn : (is_as ? aspl.pw * aspl.ppw : c.ni * 16 * c.wn);
   a.tiles_m = cdiv(a.M, BM);
   a.tiles_n = is_as ? aspl.tiles_n : cdiv(a.npad, BN);
   a.chunks_per_split = cdiv(a.nchunks, best_sk);
@@ -1354,7 +1390,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     a.gn_hw = hw_out;
   }
   // LayerNorm row sums of the output for the consumer GEMM (Epi::tile_plain_lnr / the K-split kernels' epilogue)
-  if (d->ln_rows_out && !a.ph_on && zdim == 1 && Epi::plain(a) && !gn_cp && (is_as || c.wm * c.wn > 1 || c.nbuf > 0)) {
+  if (d->ln_rows_out && !is_bt && !a.ph_on && zdim == 1 && Epi::plain(a) && !gn_cp && (is_as || c.wm * c.wn > 1 || c.nbuf > 0)) {
     // (K-split kernels: one slot per N tile; A-stationary: one per 16 * NI columns of its single pass, else none)
     const int slots = is_as ? (aspl.npass == 1 ? cdiv(a.npad, astat_config_ni(best - kNumCfgs) * 16) : 99) : a.tiles_n * c.wn;
     if (slots <= 8) {
@@ -1424,8 +1460,12 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     if (a.xm_pm) grid = dim3(8 * a.xm_mi * a.xm_nj, nph, 1);
   }
   if (is_as) return astat_launch(ctx, a, best - kNumCfgs, aspl, grid, stream);
+  int rc;
+  if (is_bt) rc = bt_launch(ctx, a, best - bt0, grid, stream);
+  else {
   hipLaunchKernelGGL((a.ln_u && !a.lnr_in) ? c.fn_ln : (a.x3 ? c.fn_app : c.fn), grid, dim3(c.nbuf ? 512 : c.wm * c.wn * 64), 0, stream, a);
-  int rc = upk_check_launch(ctx, "igemm");
+  rc = upk_check_launch(ctx, "igemm");
+  }
   if (rc) return rc;
   if (zdim > 1 && gn_apply) {
     GnApply g;

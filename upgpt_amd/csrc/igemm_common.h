@@ -601,4 +601,11 @@ int astat_config_ni(int c);
 bool astat_plan(const upk_ctx* ctx, const IgemmArgs& a, int c, int ppw_req, AsPlan* pl);
 int astat_launch(upk_ctx* ctx, IgemmArgs& a, int c, const AsPlan& pl, dim3 grid, hipStream_t stream);
 
+// bigtile.hip: the big-tile family (configurations behind the A-stationary ones): 4 waves, one per SIMD, 256x256 /
+// 256x128 / 128x256 block tiles for launches with at least one tile per CU
+int bt_num_configs();
+const char* bt_config_name(int c);
+void bt_tile(int c, int* bm, int* bn, int* occ, int* mi, int* ni);
+int bt_launch(upk_ctx* ctx, const IgemmArgs& a, int c, dim3 grid, hipStream_t stream);
+
 }  // namespace upkd

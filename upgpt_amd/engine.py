@@ -315,7 +315,7 @@ class Emitter:
                 ent = cache.get(key[:-3])  # (statistics by-product armed on a shape that was tuned without it)
             if ent is None and not tune_missing and key.endswith("_lnr"):
                 ent = cache.get(key[:-4])  # (tuned as a plain GEMM; usable only if that choice does not split K)
-                if ent is not None and int(ent[1]) != 1 and int(ent[0]) < self.lib.upk_conv_num_configs() - self._n_as():
+                if ent is not None and int(ent[1]) != 1 and not self._is_as(int(ent[0])):
                     ent = None
             if ent is None and tune_missing:
                 cfg, sk, best_us, dflt_us = self.ctx.conv_autotune(d, reps or int(os.environ.get("UPGPT_TUNE_REPS", "5")))
@@ -329,14 +329,10 @@ class Emitter:
                 d.tune_cfg, d.tune_splitk = int(ent[0]) + 1, int(ent[1])
         return hits, tuned, missing
 
-    def _n_as(self):
-        """Number of A-stationary configurations (the tail of the library's configuration list: their second tuning
-        slot is output-column passes per workgroup, not a split-K factor)."""
-        n = self.lib.upk_conv_num_configs()
-        k = 0
-        while k < n and self.lib.upk_conv_config_name(n - 1 - k).decode().startswith("as"):
-            k += 1
-        return k
+    def _is_as(self, cfg):
+        """Whether configuration `cfg` belongs to the A-stationary family (their second tuning slot is output-column
+        passes per workgroup, not a split-K factor)."""
+        return 0 <= cfg < self.lib.upk_conv_num_configs() and self.lib.upk_conv_config_name(cfg).decode().startswith("as")
 
     def alloc(self, *shape, dtype=torch.float16, zero=False):
         t = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=self.dev)
