@@ -10,3 +10,4 @@ mkdir -p profiles; cp gpurun_out/r03_igemm_traffic.json profiles/r03_igemm_traff
 timeout 900 python bench.py --steps 5 --warmup 2 > gpurun_out/bench_r03.json 2> gpurun_out/bench_r03.err; tail -c 900 gpurun_out/bench_r03.json
 bash scripts/gpu_prof.sh > gpurun_out/prof.log 2>&1
 bash scripts/gpu_optrace.sh 32 32 > /dev/null 2>&1; tail -8 gpurun_out/ot_table_32x32.txt
+bash scripts/gpu_optrace_vae.sh 32 32 > /dev/null 2>&1; tail -8 gpurun_out/ot_vae_32x32.txt
