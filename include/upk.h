@@ -334,7 +334,11 @@ int upk_conv_autotune(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream, i
 /* Forces a tile configuration / split-K factor for the next launches (tuning
  * and tests). cfg < 0 and splitk <= 0 restore the heuristic. */
 int upk_conv_override(upk_ctx* ctx, int cfg, int splitk);
-/* Number of compiled tile configurations, and a description of one. */
+/* Number of compiled tile configurations, and a description of one.  Three families, in this order (tuning files
+ * store indices: a family is only ever appended): the implicit-GEMM kernels ("4x4x2x2k2[wN]": classic and
+ * wave-specialised), the A-stationary Linears ("as2x7p8": 1x1 only; the split-K slot means output-column passes per
+ * workgroup) and the big-tile convs ("bt4x8x4x2n4": launches with at least one tile per CU, plain epilogues unless K
+ * is split).  A configuration that cannot run a descriptor is refused (UPK_ESHAPE), never approximated. */
 int upk_conv_num_configs(void);
 const char* upk_conv_config_name(int cfg);
 

@@ -559,6 +559,8 @@ def test_qkv_gemm_with_transposed_v(ctx):
 
 @pytest.mark.parametrize("d,nq,nkv,heads", [(32, 768, 768, 8), (64, 192, 87, 8), (128, 48, 48, 8), (128, 12, 12, 8),
                                             (32, 100, 87, 2), (512, 200, 200, 1),
+                                            # d >= 256 (VAE mid-block): 1 / 2 / 4 waves per workgroup by launch size
+                                            (512, 1024, 1024, 1), (256, 600, 130, 16), (256, 1024, 96, 16),
                                             # LDS-staged K/V tiles (nkv % 64 == 0, >= 256): QT=2 and QT=1, ragged nq
                                             (32, 1024, 1024, 32), (32, 1000, 256, 3), (64, 256, 256, 8), (64, 200, 320, 40)])
 def test_attention(ctx, d, nq, nkv, heads):

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   const int bh = blockIdx.x;  // (all query blocks of one (sample, head) on one XCD: its K / V cross the fabric once)
   const int b = bh / a.heads;
   const int h = bh - b * a.heads;
-  const int q0 = (blockIdx.y * 4 + wave) * 16 * QT;
+  const int q0 = (blockIdx.y * (blockDim.x >> 6) + wave) * 16 * QT;  // (1, 2 or 4 waves per workgroup: no wave talks to another)
   if (q0 >= a.nq) return;
   const f16* kbase = a.k + b * a.kbs + h * D + g * 8;
   const f16* vbase = a.vt + ((long)(b * a.heads + h) * D + c) * a.vt_ld + g * 4;
@@ -563,8 +563,20 @@ static int attention_impl(upk_ctx* ctx, const void* q, int ldq, long long qbs, c
     case 32: UPK_ATTN(32, 1) break;
     case 64: UPK_ATTN(64, 1) break;
     case 128: UPK_ATTN(128, 1) break;
-    case 256: hipLaunchKernelGGL((attn_kernel<256, 1, 1>), grid, block, 0, stream, a); break;
-    case 512: hipLaunchKernelGGL((attn_kernel<512, 0, 1>), grid, block, 0, stream, a); break;
+    case 256:
+    case 512: {
+      // the VAE mid-block attention (one head, d = 512, 1024 tokens: model.py:180-196): every wave streams the whole K / V^T
+      // of its sample through the CU's vector-memory path, so fewer waves per workgroup until every CU has work
+      // (B = 8: 128 workgroups of 4 waves -> 512 of 1)
+      int wpb = 4;
+      static const int wpb_env = getenv("UPK_ATTN_WPB") ? atoi(getenv("UPK_ATTN_WPB")) : 0;  // dev
+      while (wpb > 1 && (long)batch * heads * ((n_q + 16 * wpb - 1) / (16 * wpb)) < 2L * ctx->num_cus) wpb >>= 1;
+      if (wpb_env) wpb = wpb_env;
+      const dim3 g2(batch * heads, (n_q + 16 * wpb - 1) / (16 * wpb)), b2(64 * wpb);
+      if (d == 256) hipLaunchKernelGGL((attn_kernel<256, 1, 1>), g2, b2, 0, stream, a);
+      else hipLaunchKernelGGL((attn_kernel<512, 0, 1>), g2, b2, 0, stream, a);
+      break;
+    }
     default: return upk_fail(ctx, UPK_ESHAPE, "attention: head dim %d not in {32,64,128,256,512}", d);
   }
 #undef UPK_ATTN
