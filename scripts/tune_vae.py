@@ -2,7 +2,7 @@
 big-tile family, with realistic activations in the plan's buffers (a decode of random latents runs first: the MFMA rate
 depends on the operand data, all-zero buffers flatter some configurations), and writes the merged tuning cache.
 
-    python scripts/tune_vae.py [out.json] [min_M]
+    python scripts/tune_vae.py [out.json] [min_M] [B,h,w ...]     (default shapes: 8,32,32 8,32,24)
 """
 import contextlib, io, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,7 +26,8 @@ def decode_ms(vp, z, n=10):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-for (B, h, w) in [(8, 32, 32), (8, 32, 24)]:
+shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[3:]] or [(8, 32, 32), (8, 32, 24)]
+for (B, h, w) in shapes:
     z = torch.randn(B, 4, h, w)
     vp = fs._decode_plan(B, h, w, 0.18215)
     before = decode_ms(vp, z)
