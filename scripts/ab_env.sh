@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B on one box: UNet forward (graph replay, B=8, latent AB_HW=32x32) under VAR=value for each value, interleaved twice.
+# A/B on one box: UNet forward (graph replay, B=AB_B (8), latent AB_HW=32x32) under VAR=value for each value, interleaved twice.
 #   bash scripts/ab_env.sh UPGPT_GN_REDUCE_APPLY 0 1
 R=$GRAFT_REPO_ROOT; cd $R
 VAR=$1; shift
@@ -15,8 +15,9 @@ with contextlib.redirect_stdout(io.StringIO()):
 synth.fill_module_(model); model = model.cuda()
 unet = model.model.diffusion_model
 HW = tuple(int(v) for v in os.environ.get("AB_HW", "32x32").split("x"))
-inp = synth.synth_inputs(8, HW, 4, 87, 768, seed=0, text_only=True)
-pl = unet.plan(8, HW[0], HW[1], 87, 50, "sampler")
+B = int(os.environ.get("AB_B", "8"))
+inp = synth.synth_inputs(B, HW, 4, 87, 768, seed=0, text_only=True)
+pl = unet.plan(B, HW[0], HW[1], 87, 50, "sampler")
 pl.load_x_nchw(inp["x_T"].cuda(), 0, 0); pl.load_x_nchw(inp["c_concat"].cuda(), 4, pl.cin_pad)
 pl.load_context(inp["c_crossattn"].cuda()); pl.t_rows.copy_(torch.arange(981, 0, -20, dtype=torch.float32)[:50])
 pl.prep.run()
