@@ -1,8 +1,8 @@
 """Big-tile conv family (upgpt_amd/csrc/bigtile.hip; configurations "bt<MI>x<NI>x<WM>x<WN>n<NBUF>" of
 upk_conv_config_name) through the C ABI: every configuration against F.conv2d on VAE-decoder-like shapes (many tiles
 per CU, ragged tile edges, two-source concat, stride 2, nearest-2x upsample as four phase convs, split-K), bit-identity
-with the wave-specialised family for the same split, the GroupNorm channel partials of the plain epilogue, and the
-refusals (non-plain epilogues without split-K, appended K segment)."""
+with the wave-specialised family for the same split, the GroupNorm channel partials / LayerNorm row sums of the plain epilogue, the
+general epilogue of the 4-wave configurations and the refusals (8-wave + non-plain unsplit, appended K segment)."""
 import math
 
 import pytest
@@ -147,30 +147,96 @@ def test_groupnorm_partials_from_the_epilogue(ctx):
     assert ran >= 3
 
 
-def test_refusals(ctx):
-    """Plain epilogues only unless K is split (the reduce pass then runs any epilogue); no appended K segment."""
-    B, H, W, cin, cout = 1, 16, 16, 64, 128
+@pytest.mark.parametrize("flags,f32", [(L.F_SILU, False), (L.F_QUICKGELU, False), (0, True)])
+def test_other_epilogues_and_the_refused_appended_segment(ctx, flags, f32):
+    """The general epilogue (SiLU, quick-GELU, fp32 output ...) exists for the 4-wave configurations (their own
+    instantiations) and for every configuration when K is split (the reduce pass runs it); the 8-wave configurations
+    refuse it unsplit.  The appended 1x1 K segment lives in the wave-specialised loader only: always refused."""
+    B, H, W, cin, cout = 1, 16, 20, 64, 160
     x = rnd(B, cin, H, W)
     w = rnd(cout, cin, 3, 3, scale=1 / math.sqrt(9 * cin))
     b = rnd(cout, scale=0.1)
-    ref = F.silu(conv_ref(x, w, b))
-    cfg = bt_cfgs(ctx)[0][0]
+    ref = conv_ref(x, w, b)
+    if flags & L.F_SILU:
+        ref = F.silu(ref)
+    if flags & L.F_QUICKGELU:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    ran = refused = 0
     try:
-        y = torch.zeros(B, H, W, cout, device=DEV, dtype=torch.float16)
-        ctx.conv_override(cfg, 1)
-        with pytest.raises(L.UpkError):
-            ctx.conv(make_desc(ctx, nhwc16(x), w, b, y, flags=L.F_SILU))
-        ctx.conv_override(cfg, 2)
-        ctx.conv(make_desc(ctx, nhwc16(x), w, b, y, flags=L.F_SILU))
-        torch.cuda.synchronize()
-        check(y.permute(0, 3, 1, 2), ref)
+        for cfg, name in bt_cfgs(ctx):
+            for sk in (1, 2):
+                y = torch.zeros(B, H, W, cout, device=DEV, dtype=torch.float32 if f32 else torch.float16)
+                ctx.conv_override(cfg, sk)
+                try:
+                    ctx.conv(make_desc(ctx, nhwc16(x), w, b, y, flags=flags | (L.F_OUT_F32 if f32 else 0)))
+                except L.UpkError:
+                    assert sk == 1, name
+                    refused += 1
+                    continue
+                torch.cuda.synchronize()
+                check(y.permute(0, 3, 1, 2), ref)
+                ran += 1
+        assert ran >= len(bt_cfgs(ctx)) + 3 and refused >= 1, (ran, refused)
         x3 = nhwc16(rnd(B, 32, H, W, seed=9))
+        y = torch.zeros(B, H, W, cout, device=DEV, dtype=torch.float16)
         d = make_desc(ctx, nhwc16(x), w, b, y)
         d.x3, d.c3, d.ld3 = x3.data_ptr(), 32, 32
         for sk in (1, 2):
-            ctx.conv_override(cfg, sk)
+            ctx.conv_override(bt_cfgs(ctx)[0][0], sk)
             with pytest.raises(L.UpkError):
                 ctx.conv(d)
+    finally:
+        ctx.conv_override(-1, 0)
+
+
+def test_geglu_and_layernorm_rows(ctx):
+    """Epilogues of the transformer Linears: GEGLU (bit-identical to the wave-specialised family's), LayerNorm row sums
+    of a plain output for a folded-LayerNorm consumer (<= 8 column slots)."""
+    import ctypes as ct
+    from test_ops_gpu import geglu_row_map
+    M, C, N = 600, 128, 512
+    x = rnd(M, C).half()
+    names = [ctx.lib.upk_conv_config_name(i).decode() for i in range(ctx.lib.upk_conv_num_configs())]
+    try:
+        w = rnd(N, C, scale=1 / math.sqrt(C)); b = rnd(N, scale=0.1)
+        rm = geglu_row_map(N // 2).to(DEV)
+        outs = []
+        for cfg in [names.index("2x4x4x1k2w3")] + [c for c, _ in bt_cfgs(ctx)]:
+            y = torch.zeros(1, M, 1, N // 2, device=DEV, dtype=torch.float16)
+            d = make_desc(ctx, x.view(1, M, 1, C), w.view(N, C, 1, 1), b, y, flags=L.F_GEGLU, n_out=N // 2, row_map=rm)
+            ctx.conv_override(cfg, 1)
+            try:
+                ctx.conv(d)
+            except L.UpkError:
+                continue  # (8-wave configurations: plain epilogues only)
+            torch.cuda.synchronize()
+            outs.append(y.clone())
+        v, g = (x.float() @ w.half().float().t() + b).chunk(2, dim=1)
+        check(outs[0].view(M, N // 2), v * F.gelu(g))
+        assert len(outs) >= 4
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0])
+        w2 = rnd(256, C, scale=1 / math.sqrt(C)); b2 = rnd(256, scale=0.1)
+        took = 0
+        for cfg, name in bt_cfgs(ctx):
+            y = torch.zeros(1, M, 1, 256, device=DEV, dtype=torch.float16)
+            rows = torch.zeros(8, M, 2, device=DEV)
+            d = make_desc(ctx, x.view(1, M, 1, C), w2.view(256, C, 1, 1), b2, y)
+            d.ln_rows_out = rows.data_ptr()
+            ctx.conv_override(cfg, 1)
+            slots = ct.c_int(0)
+            ctx._chk(ctx.lib.upk_conv_ln_rows(ctx.h, ct.byref(d), ct.byref(slots)))
+            assert 0 <= slots.value <= 8, name
+            ctx.conv(d)
+            torch.cuda.synchronize()
+            yf = y.view(M, 256).float()
+            check(yf, x.float() @ w2.half().float().t() + b2)
+            if slots.value:
+                got = rows[:slots.value].sum(0)
+                assert torch.allclose(got[:, 0], yf.sum(1), rtol=1e-3, atol=1e-2), name
+                assert torch.allclose(got[:, 1], (yf * yf).sum(1), rtol=1e-3, atol=1e-2), name
+                took += 1
+        assert took >= 3
     finally:
         ctx.conv_override(-1, 0)
 

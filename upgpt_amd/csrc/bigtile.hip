@@ -25,9 +25,9 @@
 // 115-130 us on all-zero ones — an MFMA-bound launch runs at the clock the chip sustains under its operands' switching
 // power, ~1.05 PFLOP/s here.
 // Same operand layout, weight packing ([K/32][n_pad][32]), tile order (tile_map), split-K slabs and epilogues
-// (Epi::tile_plain / tile_plain_cp) as igemm.hip: plain epilogues (any epilogue when K is split: the reduce pass runs
-// it), no appended K segment, no fragment-side LayerNorm fold; results are bit-identical to the other families' for
-// the same split.
+// (Epi) as igemm.hip: plain epilogues in every configuration, all others in the 4-wave ones (own instantiations) or
+// through the reduce pass when K is split; no appended K segment, no fragment-side LayerNorm fold (row statistics from
+// the producer are taken: IgemmArgs::lnr_in); results are bit-identical to the other families' for the same split.
 #include <type_traits>
 
 #include "igemm_common.h"
@@ -59,7 +59,7 @@ __device__ __forceinline__ void bt_wait_lgkm(int n) {
 // the value is used only after the preceding (volatile) wait: volatile asm statements keep their order
 __device__ __forceinline__ void bt_tie(f16x8& v) { asm volatile("" : "+v"(v)); }
 
-template <int MI, int NI, int WM, int WN, int NBUF, bool LA>
+template <int MI, int NI, int WM, int WN, int NBUF, bool LA, bool FE = false>
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_bt_kernel(const IgemmArgs a) {
   constexpr int NW = WM * WN;  // waves: 4 (two workgroups per CU) or 8 (one)
   static_assert(NW == 4 || NW == 8, "two waves per SIMD");
@@ -354,24 +354,37 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2, 
     }
     return;
   }
-  // plain epilogues only (bias + timestep row vector + residual -> fp16 NHWC, optionally the GroupNorm channel partials):
-  // the host refuses the family for anything else unless K is split (the reduce pass then runs the epilogue)
-  if (a.gn_cp) Epi::tile_plain_cp<MI, NI, WM, WN>(a, m0, mw, nw, lc, lg, acc, wm, wn, (float*)smem, a.M);
-  else Epi::tile_plain<MI, NI>(a, mw, nw, lc, lg, acc, a.M);
+  if constexpr (FE) {
+    // every epilogue of the shared Epi::tile (SiLU / quick-GELU, fp32 / NCHW output, transposed V tail, GEGLU): its
+    // own instantiation — compiled into the kernels above, the general per-fragment path costs their K loops 5-50 %
+    // (registers live across the loop; 512 -> 512 at 64x64: 144 -> 152 us on the 4-wave, -> 219 us on the 8-wave tiles)
+    Epi::tile<MI, NI, WM, WN>(a, m0, mw, nw, lc, lg, acc, wm, wn, (float*)smem, a.M);
+  } else {
+    // plain epilogues (bias + timestep row vector + residual -> fp16 NHWC, optionally with the GroupNorm channel
+    // partials or the LayerNorm row sums of what is stored); anything else goes to the FE instantiation of the
+    // configuration, or — when K is split — to the reduce pass
+    if (a.gn_cp) Epi::tile_plain_cp<MI, NI, WM, WN>(a, m0, mw, nw, lc, lg, acc, wm, wn, (float*)smem, a.M);
+    else if (a.lnr_out) Epi::tile_plain_lnr<MI, NI>(a, mw, nw, lc, lg, acc, a.M);
+    else Epi::tile_plain<MI, NI>(a, mw, nw, lc, lg, acc, a.M);
+  }
 }
 
 struct BtCfg {
   int mi, ni, wm, wn, nbuf;
   const char* name;
   void (*fn)(const IgemmArgs);
+  void (*fn_fe)(const IgemmArgs);  // instantiation with every epilogue, or nullptr
 };
 #define BTC(MI, NI, WM, WN, NB, LA) \
-  {MI, NI, WM, WN, NB, "bt" #MI "x" #NI "x" #WM "x" #WN "n" #NB, igemm_bt_kernel<MI, NI, WM, WN, NB, LA>}
+  {MI, NI, WM, WN, NB, "bt" #MI "x" #NI "x" #WM "x" #WN "n" #NB, igemm_bt_kernel<MI, NI, WM, WN, NB, LA>, nullptr}
+#define BTCF(MI, NI, WM, WN, NB, LA) \
+  {MI, NI, WM, WN, NB, "bt" #MI "x" #NI "x" #WM "x" #WN "n" #NB, igemm_bt_kernel<MI, NI, WM, WN, NB, LA>, \
+   igemm_bt_kernel<MI, NI, WM, WN, NB, LA, true>}
 const BtCfg kBt[] = {
-    // 4 waves, two workgroups per CU (72 KB rings)
-    BTC(8, 4, 2, 2, 3, false),  // 256x128
-    BTC(4, 8, 2, 2, 3, false),  // 128x256
-    BTC(4, 8, 4, 1, 3, false),  // 256x128 (wave 64x128: A rows private, B shared)
+    // 4 waves, two workgroups per CU (72 KB rings); also instantiated with the general epilogue
+    BTCF(8, 4, 2, 2, 3, false),  // 256x128
+    BTCF(4, 8, 2, 2, 3, false),  // 128x256
+    BTCF(4, 8, 4, 1, 3, false),  // 256x128 (wave 64x128: A rows private, B shared)
     // 8 waves, one workgroup per CU, fragments of the next stage read ahead
     BTC(4, 8, 4, 2, 4, true),  // 256x256, 128 KB ring
     BTC(8, 4, 2, 4, 4, true),  // 256x256 (wave 128x64)
@@ -384,7 +397,9 @@ constexpr int kNumBt = sizeof(kBt) / sizeof(kBt[0]);
 
 int bt_num_configs() { return kNumBt; }
 const char* bt_config_name(int c) { return (c >= 0 && c < kNumBt) ? kBt[c].name : "?"; }
-void bt_tile(int c, int* bm, int* bn, int* occ, int* mi, int* ni) {
+bool bt_full_epilogue(int c) { return kBt[c].fn_fe != nullptr; }
+void bt_tile(int c, int* bm, int* bn, int* occ, int* mi, int* ni, int* wn) {
+  *wn = kBt[c].wn;
   *bm = kBt[c].mi * 16 * kBt[c].wm;
   *bn = kBt[c].ni * 16 * kBt[c].wn;
   *occ = kBt[c].wm * kBt[c].wn == 4 ? 2 : 1;
@@ -392,7 +407,10 @@ void bt_tile(int c, int* bm, int* bn, int* occ, int* mi, int* ni) {
   *ni = kBt[c].ni;
 }
 int bt_launch(upk_ctx* ctx, const IgemmArgs& a, int c, dim3 grid, hipStream_t stream) {
-  hipLaunchKernelGGL(kBt[c].fn, grid, dim3(kBt[c].wm * kBt[c].wn * 64), 0, stream, a);
+  // (split launches write fp32 slabs: no epilogue in the kernel)
+  const bool fe = !a.partial && !Epi::plain(a);
+  if (fe && !kBt[c].fn_fe) return upk_fail(ctx, UPK_ESHAPE, "conv: %s has no general-epilogue instantiation", kBt[c].name);
+  hipLaunchKernelGGL(fe ? kBt[c].fn_fe : kBt[c].fn, grid, dim3(kBt[c].wm * kBt[c].wn * 64), 0, stream, a);
   return upk_check_launch(ctx, "igemm_bt");
 }
 

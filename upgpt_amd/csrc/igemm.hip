@@ -1287,11 +1287,12 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   const int bt0 = kNumCfgs + astat_num_configs();
   const bool bt_able = !a.x3 && !(a.ln_u && !a.lnr_in);  // (no appended segment, no fragment-side LayerNorm fold)
   bool is_bt = want_cfg >= bt0;
-  int bt_bm = 0, bt_bn = 0, bt_occ = 1, bt_mi = 0, bt_ni = 0;
+  int bt_bm = 0, bt_bn = 0, bt_occ = 1, bt_mi = 0, bt_ni = 0, bt_wn = 1;
   if (is_bt) {
-    bt_tile(want_cfg - bt0, &bt_bm, &bt_bn, &bt_occ, &bt_mi, &bt_ni);
+    bt_tile(want_cfg - bt0, &bt_bm, &bt_bn, &bt_occ, &bt_mi, &bt_ni, &bt_wn);
     const int sk = want_sk > 0 ? want_sk : 1;
-    if (!bt_able || (sk == 1 && !Epi::plain(a)) || (a.ln_u && sk > 1) || (sk > 1 && (slab * sk > ctx->ws_bytes || a.nchunks / sk < 4)))
+    if (!bt_able || (sk == 1 && !Epi::plain(a) && !bt_full_epilogue(want_cfg - bt0)) || (geglu && ((bt_ni * 16) % 64 != 0)) ||
+        (a.ln_u && sk > 1) || (sk > 1 && (slab * sk > ctx->ws_bytes || a.nchunks / sk < 4)))
       return upk_fail(ctx, UPK_ESHAPE, "conv: big-tile configuration %s (split-K %d) does not fit this launch",
                       bt_config_name(want_cfg - bt0), sk);
     best = want_cfg;
@@ -1326,8 +1327,8 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     // cost model for the big-tile family: MFMA-bound stages (16 cycles per fragment MFMA, four SIMDs in parallel, the
     // workgroups of a CU taking turns) + prologue / epilogue per tile; only where every CU gets a tile
     for (int c = 0; c < bt_num_configs(); ++c) {
-      int bm, bn, occ, mi, ni;
-      bt_tile(c, &bm, &bn, &occ, &mi, &ni);
+      int bm, bn, occ, mi, ni, wn;
+      bt_tile(c, &bm, &bn, &occ, &mi, &ni, &wn);
       if (geglu && ((ni * 16) % 64 != 0)) continue;
       const long tiles = (long)cdiv(a.M, bm) * cdiv(a.npad, bn) * nph;
       if (tiles < ctx->num_cus) continue;
@@ -1338,7 +1339,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
         best = bt0 + c;
         best_sk = 1;
         is_bt = true;
-        bt_bm = bm, bt_bn = bn, bt_occ = occ, bt_mi = mi, bt_ni = ni;
+        bt_bm = bm, bt_bn = bn, bt_occ = occ, bt_mi = mi, bt_ni = ni, bt_wn = wn;
       }
     }
   }
@@ -1390,9 +1391,10 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     a.gn_hw = hw_out;
   }
   // LayerNorm row sums of the output for the consumer GEMM (Epi::tile_plain_lnr / the K-split kernels' epilogue)
-  if (d->ln_rows_out && !is_bt && !a.ph_on && zdim == 1 && Epi::plain(a) && !gn_cp && (is_as || c.wm * c.wn > 1 || c.nbuf > 0)) {
+  if (d->ln_rows_out && !a.ph_on && zdim == 1 && Epi::plain(a) && !gn_cp && (is_as || is_bt || c.wm * c.wn > 1 || c.nbuf > 0)) {
     // (K-split kernels: one slot per N tile; A-stationary: one per 16 * NI columns of its single pass, else none)
-    const int slots = is_as ? (aspl.npass == 1 ? cdiv(a.npad, astat_config_ni(best - kNumCfgs) * 16) : 99) : a.tiles_n * c.wn;
+    const int slots = is_as ? (aspl.npass == 1 ? cdiv(a.npad, astat_config_ni(best - kNumCfgs) * 16) : 99)
+                            : a.tiles_n * (is_bt ? bt_wn : c.wn);
     if (slots <= 8) {
       a.lnr_out = d->ln_rows_out;
       if (lnr_slots) *lnr_slots = slots;

@@ -605,7 +605,8 @@ int astat_launch(upk_ctx* ctx, IgemmArgs& a, int c, const AsPlan& pl, dim3 grid,
 // 256x128 / 128x256 block tiles for launches with at least one tile per CU
 int bt_num_configs();
 const char* bt_config_name(int c);
-void bt_tile(int c, int* bm, int* bn, int* occ, int* mi, int* ni);
+void bt_tile(int c, int* bm, int* bn, int* occ, int* mi, int* ni, int* wn);
+bool bt_full_epilogue(int c);  // the configuration also exists with the general epilogue (Epi::tile)
 int bt_launch(upk_ctx* ctx, const IgemmArgs& a, int c, dim3 grid, hipStream_t stream);
 
 }  // namespace upkd
