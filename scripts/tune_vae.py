@@ -49,4 +49,30 @@ for (B, h, w) in shapes:
     vp = fs._decode_plan(B, h, w, 0.18215)
     after = decode_ms(vp, z)
     print("vae decode B=%d %dx%d: %.3f -> %.3f ms (%d launches re-pinned)" % (B, h, w, before, after, changed), flush=True)
+# the encoder (img2img / inpainting paths): images of 8 x the latent size
+if os.environ.get("TUNE_VAE_ENCODER", "1") == "1":
+    for (B, h, w) in shapes:
+        x = torch.randn(B, 3, 8 * h, 8 * w).clamp(-1, 1)
+        ep = fs._encode_plan(B, 8 * h, 8 * w)
+
+        def enc_ms(ep, n=5):
+            for _ in range(2): ep.run(x)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(n): ep.run(x)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+        before = enc_ms(ep)
+        seen = set()
+        for d, key in ep.convs:
+            M = int(key.split("_")[0][1:])
+            if M < min_m or key in seen:
+                continue
+            seen.add(key)
+            old = TUNE_CACHE.get(key)
+            cfg, sk, best_us, dflt_us = ep.ctx.conv_autotune(d, 4)
+            print("%-52s %s sk %d  %.1f us (was %s)" % (key, ep.ctx.lib.upk_conv_config_name(cfg).decode(), sk, best_us, old), flush=True)
+            TUNE_CACHE.put(key, cfg, sk, best_us, dflt_us)
+        TUNE_CACHE.save(out)
+        fs._enc_plans.clear()
+        print("vae encode B=%d %dx%d px: %.3f -> %.3f ms" % (B, 8 * h, 8 * w, before, enc_ms(fs._encode_plan(B, 8 * h, 8 * w))), flush=True)
 print("entries:", len(TUNE_CACHE.d), "->", out)
