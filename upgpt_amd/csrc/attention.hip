@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void attn_qproj_kernel(const AttnArgs a, const
   const int bh = blockIdx.y;
   const int b = bh / a.heads;
   const int h = bh - b * a.heads;
-  const int q0 = (blockIdx.x * 4 + wave) * 16 * QT;
+  const int q0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 16 * QT;  // (1, 2 or 4 independent waves per workgroup)
   if (q0 >= a.nq) return;
   const f16* kbase = a.k + b * a.kbs + h * D + g * 8;
   const f16* vbase = a.vt + ((long)(b * a.heads + h) * D + c) * a.vt_ld + g * 4;
@@ -508,6 +508,19 @@ __global__ __launch_bounds__(256) void attn_lds_kernel(const AttnArgs a) {
 
 }  // namespace
 
+// Waves per workgroup of the attention kernels whose waves are independent (no LDS, no barrier): 4, halved while the
+// launch has fewer than two workgroups per CU.  The UNet's 8x8 / 4x4-level launches are 64 (sample, head) pairs x 1-4
+// query groups: as 64 workgroups of 4 waves they load K / V through 64 CUs' vector-memory paths, as 256 of one wave
+// through all of them (forward 3.000 -> 2.966 ms; the VAE's d = 512 mid-block attention 0.40 -> 0.28 ms).
+// UPK_ATTN_WPB=n forces n (dev A/B).
+static int attn_waves_per_block(const upk_ctx* ctx, int bh, int n_q, int qt) {
+  static const int wpb_env = getenv("UPK_ATTN_WPB") ? atoi(getenv("UPK_ATTN_WPB")) : 0;
+  if (wpb_env == 1 || wpb_env == 2 || wpb_env == 4) return wpb_env;
+  int wpb = 4;
+  while (wpb > 1 && (long)bh * ((n_q + 16 * qt * wpb - 1) / (16 * qt * wpb)) < 2L * ctx->num_cus) wpb >>= 1;
+  return wpb;
+}
+
 static int attention_impl(upk_ctx* ctx, const void* q, int ldq, long long qbs, const void* k, int ldk, long long kbs,
                           const void* vt, int vt_ld, void* out, int ldo, long long obs, int batch, int heads, int n_q,
                           int n_kv, int d, float scale, int causal, upk_stream stream_) {
@@ -554,6 +567,14 @@ static int attention_impl(upk_ctx* ctx, const void* q, int ldq, long long qbs, c
     }
     return upk_check_launch(ctx, "attention_lds");
   }
+  // the kernels below keep no state between waves: fewer waves per workgroup while that gives more CUs work
+  {
+    const int wpb = attn_waves_per_block(ctx, batch * heads, n_q, d <= 128 ? qt : 1);
+    if (d <= 128) {
+      grid = dim3(batch * heads, (n_q + 16 * qt * wpb - 1) / (16 * qt * wpb));
+      block = dim3(64 * wpb);
+    }
+  }
 #define UPK_ATTN(D_, QR_)                                                                         \
   if (qt == 2)                                                                                    \
     hipLaunchKernelGGL((attn_kernel<D_, QR_, (D_ <= 128 ? 2 : 1)>), grid, block, 0, stream, a);  \
@@ -568,10 +589,7 @@ static int attention_impl(upk_ctx* ctx, const void* q, int ldq, long long qbs, c
       // the VAE mid-block attention (one head, d = 512, 1024 tokens: model.py:180-196): every wave streams the whole K / V^T
       // of its sample through the CU's vector-memory path, so fewer waves per workgroup until every CU has work
       // (B = 8: 128 workgroups of 4 waves -> 512 of 1)
-      int wpb = 4;
-      static const int wpb_env = getenv("UPK_ATTN_WPB") ? atoi(getenv("UPK_ATTN_WPB")) : 0;  // dev
-      while (wpb > 1 && (long)batch * heads * ((n_q + 16 * wpb - 1) / (16 * wpb)) < 2L * ctx->num_cus) wpb >>= 1;
-      if (wpb_env) wpb = wpb_env;
+      const int wpb = attn_waves_per_block(ctx, batch * heads, n_q, 1);
       const dim3 g2(batch * heads, (n_q + 16 * wpb - 1) / (16 * wpb)), b2(64 * wpb);
       if (d == 256) hipLaunchKernelGGL((attn_kernel<256, 1, 1>), g2, b2, 0, stream, a);
       else hipLaunchKernelGGL((attn_kernel<512, 0, 1>), g2, b2, 0, stream, a);
@@ -637,12 +655,10 @@ extern "C" int upk_attention_qproj_f16(upk_ctx* ctx, const void* x, int ldx, lon
   p.ln_dim = ln_dim;
   p.eps = ln_eps;
   upk_prof_scope prof(ctx, UPK_CLS_ATTN, stream);
-  if (d == 32) {
-    dim3 grid((n_q + 127) / 128, batch * heads);
-    hipLaunchKernelGGL((attn_qproj_kernel<32, 2>), grid, dim3(256), 0, stream, a, p);
-  } else {
-    dim3 grid((n_q + 63) / 64, batch * heads);  // (two query groups per wave measured slower: 21.5 vs 17.8 us at 256 x 8 heads)
-    hipLaunchKernelGGL((attn_qproj_kernel<64, 1>), grid, dim3(256), 0, stream, a, p);
-  }
+  const int qt = d == 32 ? 2 : 1;  // (d = 64: two query groups per wave measured slower: 21.5 vs 17.8 us at 256 x 8 heads)
+  const int wpb = attn_waves_per_block(ctx, batch * heads, n_q, qt);
+  const dim3 grid((n_q + 16 * qt * wpb - 1) / (16 * qt * wpb), batch * heads), block(64 * wpb);
+  if (d == 32) hipLaunchKernelGGL((attn_qproj_kernel<32, 2>), grid, block, 0, stream, a, p);
+  else hipLaunchKernelGGL((attn_qproj_kernel<64, 1>), grid, block, 0, stream, a, p);
   return upk_check_launch(ctx, "attention_qproj");
 }
