@@ -210,7 +210,70 @@ def top_kernel_roofline(model, wl, reps=40):
             "algorithmic_flops": body.flops[i], "us_back_to_back": us, "achieved": tf, "frac": tf / PEAK_MFMA_F16_TFLOPS}
 
 
-TRAFFIC_FILE = "profiles/r03_igemm_traffic.json"
+def dominant_kernel_roofline(model, wl, reps=20, ncand=8):
+    """The (kernel, shape) with the largest share of the forward's GPU time, timed IN SITU: the launches of the forward
+    are grouped by label (= shape signature: launches of one group run the same kernel on the same grid), and for the
+    `ncand` groups with the most FLOPs x launches the captured forward is replayed with and without the group (HIP
+    events on the launch stream, median of 3 back-to-back pairs); the group with the largest difference is reported
+    with its per-launch time inside the forward — cold weights, freshly produced activations, its split-K reduce and
+    statistics work included.  (roofline.top_kernel is the other figure: the most-FLOPs launch, warm and isolated.)"""
+    import ctypes as C
+    unet = model.model.diffusion_model
+    with model.ema_scope():
+        plan = unet.plan(wl.B, wl.hw[0], wl.hw[1], 87, wl.S, "sampler")
+        body, ctx = plan.body, plan.ctx
+        groups = {}
+        for i, (f, c, lab) in enumerate(zip(body.flops, body.cls, body.labels)):
+            if c.startswith("igemm") or c == "attention":
+                groups.setdefault(lab, []).append(i)
+        exe = lambda f, lab: f * 4.0 / 9.0 if lab.endswith("_ph") else float(f)
+        # candidates: the groups a static estimate (launches x (6 us + FLOPs at 0.4 PFLOP/s)) ranks highest
+        est = lambda lab, idx: sum(6e-6 + exe(body.flops[i], lab) / 0.4e15 for i in idx)
+        cands = sorted(groups.items(), key=lambda kv: -est(*kv))[:ncand]
+        s = torch.cuda.Stream(device=plan.dev)
+
+        def timed(skip_idx):
+            with torch.cuda.stream(s):
+                sp = s.cuda_stream
+                ctx._chk(ctx.lib.upk_graph_begin(ctx.h, sp))
+                body.run(sp, skip_idx=skip_idx)
+                g = C.c_void_p()
+                ctx._chk(ctx.lib.upk_graph_end(ctx.h, sp, C.byref(g)))
+                ctx._chk(ctx.lib.upk_graph_launch(ctx.h, g, sp))
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(s)
+                for _ in range(reps):
+                    ctx._chk(ctx.lib.upk_graph_launch(ctx.h, g, sp))
+                e1.record(s)
+                s.synchronize()
+                ctx.graph_destroy(g)
+                return e0.elapsed_time(e1) / reps
+
+        torch.cuda.synchronize()
+        timed(frozenset())
+        best = None
+        for lab, idx in cands:
+            diffs = []
+            for _ in range(3):
+                f = timed(frozenset())
+                diffs.append(f - timed(frozenset(idx)))
+            ms = sorted(diffs)[1]
+            if best is None or ms > best[0]:
+                best = (ms, lab, idx, f)
+        plan.prep.run()  # the ablated replays left garbage in the activations
+        torch.cuda.synchronize()
+    ms, lab, idx, full = best
+    fl = sum(exe(body.flops[i], lab) for i in idx)
+    out = {"label": lab, "launches_per_fwd": len(idx), "ms_per_fwd_in_situ": ms, "share_of_forward": ms / full,
+           "us_per_launch_in_situ": ms * 1e3 / len(idx), "method": "graph-replay difference with / without the group, "
+           "median of 3 pairs; candidates: the %d label groups a static estimate ranks highest" % len(cands)}
+    if fl:
+        tf = fl / (ms * 1e-3) / 1e12
+        out.update({"flops_per_fwd": fl, "achieved": tf, "frac": tf / PEAK_MFMA_F16_TFLOPS})
+    return out
+
+
+TRAFFIC_FILE = "profiles/r04_igemm_traffic.json"
 
 
 def igemm_traffic_bytes_per_launch():
@@ -465,6 +528,7 @@ def main():
                       "GroupNorm / LayerNorm work done inside a conv/GEMM launch (split-K reduce pass that normalises, "
                       "folded LayerNorm, statistics by-products) is timed with this class, not with the norm classes",
             "top_kernel": top_kernel_roofline(model, wl),
+            "dominant_kernel": dominant_kernel_roofline(model, wl),
             "achieved": achieved, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F16_TFLOPS,
             "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_flops_per_fwd": ig_flops, "launches_per_fwd": n_api, "kernels_per_fwd": n_k,

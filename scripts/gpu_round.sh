@@ -6,8 +6,8 @@ cd $R
 timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log
 timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; tail -2 gpurun_out/smoke.log
 bash scripts/gpu_traffic.sh > gpurun_out/traffic.log 2>&1; tail -5 gpurun_out/traffic.log
-mkdir -p profiles; cp gpurun_out/r03_igemm_traffic.json profiles/r03_igemm_traffic.json
-timeout 900 python bench.py --steps 5 --warmup 2 > gpurun_out/bench_r03.json 2> gpurun_out/bench_r03.err; tail -c 900 gpurun_out/bench_r03.json
+mkdir -p profiles; cp gpurun_out/r04_igemm_traffic.json profiles/r04_igemm_traffic.json
+timeout 900 python bench.py --steps 5 --warmup 2 > gpurun_out/bench_r04.json 2> gpurun_out/bench_r04.err; tail -c 900 gpurun_out/bench_r04.json
 bash scripts/gpu_prof.sh > gpurun_out/prof.log 2>&1
 bash scripts/gpu_optrace.sh 32 32 > /dev/null 2>&1; tail -8 gpurun_out/ot_table_32x32.txt
 bash scripts/gpu_optrace_vae.sh 32 32 > /dev/null 2>&1; tail -8 gpurun_out/ot_vae_32x32.txt

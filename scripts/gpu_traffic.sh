@@ -1,12 +1,12 @@
 #!/bin/bash
 # HBM-side traffic of the igemm kernels per launch: separate PMC passes (FETCH_SIZE, WRITE_SIZE) over N replays of
-# the captured UNet forward -> gpurun_out/r03_igemm_traffic.json (copy to profiles/; bench.py reads it from there).
+# the captured UNet forward -> gpurun_out/r04_igemm_traffic.json (copy to profiles/; bench.py reads it from there).
 mkdir -p gpurun_out; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd /tmp
 N=4
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c; rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python $R/scripts/fwd_replay.py 32 32 $N > /tmp/pmc_$c.log 2>&1 || tail -3 /tmp/pmc_$c.log
 done
-python - $N "${GRAFT_COMMIT:-$(cat $R/.commit 2>/dev/null || echo unknown)}" <<'PY' | tee $GRAFT_REPO_ROOT/gpurun_out/r03_igemm_traffic.json
+python - $N "${GRAFT_COMMIT:-$(cat $R/.commit 2>/dev/null || echo unknown)}" <<'PY' | tee $GRAFT_REPO_ROOT/gpurun_out/r04_igemm_traffic.json
 import csv, glob, sys, json
 N = int(sys.argv[1])
 raw = {}

@@ -397,8 +397,9 @@ constexpr int kNumBt = sizeof(kBt) / sizeof(kBt[0]);
 
 int bt_num_configs() { return kNumBt; }
 const char* bt_config_name(int c) { return (c >= 0 && c < kNumBt) ? kBt[c].name : "?"; }
-bool bt_full_epilogue(int c) { return kBt[c].fn_fe != nullptr; }
+bool bt_full_epilogue(int c) { return c >= 0 && c < kNumBt && kBt[c].fn_fe != nullptr; }
 void bt_tile(int c, int* bm, int* bn, int* occ, int* mi, int* ni, int* wn) {
+  if (c < 0 || c >= kNumBt) c = 0;  // (callers range-check; never index past the table)
   *wn = kBt[c].wn;
   *bm = kBt[c].mi * 16 * kBt[c].wm;
   *bn = kBt[c].ni * 16 * kBt[c].wn;

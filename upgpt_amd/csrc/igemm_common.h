@@ -609,4 +609,17 @@ void bt_tile(int c, int* bm, int* bn, int* occ, int* mi, int* ni, int* wn);
 bool bt_full_epilogue(int c);  // the configuration also exists with the general epilogue (Epi::tile)
 int bt_launch(upk_ctx* ctx, const IgemmArgs& a, int c, dim3 grid, hipStream_t stream);
 
+
+// halo.hip: the halo-patch 3x3 family (configurations behind the big-tile ones): input patch resident in LDS, weights
+// streamed into registers by eight K-splitting waves; second tuning slot = split-K factor over channel ranges
+struct HcPlan {
+  int bn, splitk, lds_bytes, cp_off;
+  int pw, part_pix, npix, ngrp, cr, nslot, cpt, mps, aps, sh_hw, sh_w;
+};
+int hc_num_configs();
+const char* hc_config_name(int c);
+int hc_config_bn(int c);
+bool hc_plan(const upk_ctx* ctx, const IgemmArgs& a, int c, int splitk, HcPlan* pl);
+int hc_launch(upk_ctx* ctx, const IgemmArgs& a, int c, const HcPlan& pl, dim3 grid, hipStream_t stream);
+
 }  // namespace upkd

@@ -42,12 +42,40 @@ class TuneCache:
         self.path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
         self.d = {}
         self.dirty = False
+        self.names = None  # configuration names the indices in the file refer to ("__configs__"), resolved by bind()
         if os.path.exists(self.path):
             try:
                 with open(self.path) as f:
                     self.d = json.load(f)
             except Exception:
                 self.d = {}
+        self.names = self.d.pop("__configs__", None)
+        self._bound = False
+
+    def bind(self, lib):
+        """Ties the stored configuration indices to THIS library's configuration list: entries are re-indexed by
+        configuration name when the file records the names it was written with ("__configs__"), and entries whose
+        configuration does not exist (any more) are dropped — they fall back to the cost model instead of pinning a
+        different kernel or an index past the table."""
+        if self._bound:
+            return
+        self._bound = True
+        n = lib.upk_conv_num_configs()
+        cur = [lib.upk_conv_config_name(i).decode() for i in range(n)]
+        if self.names is not None and self.names != cur:
+            idx = {nm: i for i, nm in enumerate(cur)}
+            remap = {i: idx.get(nm, -1) for i, nm in enumerate(self.names)}
+            for k in list(self.d):
+                c = remap.get(int(self.d[k][0]), -1)
+                if c < 0:
+                    del self.d[k]
+                else:
+                    self.d[k][0] = c
+        else:
+            for k in list(self.d):
+                if not 0 <= int(self.d[k][0]) < n:
+                    del self.d[k]
+        self.names = cur
 
     def get(self, key):
         return self.d.get(key)
@@ -58,8 +86,11 @@ class TuneCache:
         return self.d[key]
 
     def save(self, path=None):
+        out = dict(self.d)
+        if self.names is not None:
+            out["__configs__"] = self.names
         with open(path or self.path, "w") as f:
-            json.dump(self.d, f, indent=0, sort_keys=True)
+            json.dump(out, f, indent=0, sort_keys=True)
         self.dirty = False
 
 
@@ -83,6 +114,11 @@ XB_ROWS = int(os.environ.get("UPGPT_XB_ROWS", "0"))  # rows per workgroup (16 / 
 # fused head of a SpatialTransformer (csrc/xblock.hip hblock_kernel: proj_in -> norm1 -> q | k | v, one launch instead of two)
 HBLOCK = os.environ.get("UPGPT_HBLOCK", "auto")
 HBLOCK_GN = os.environ.get("UPGPT_HBLOCK_GN", "1") == "1"  # SpatialTransformer.norm applied on the tile inside that launch
+# halo-patch 3x3 family by rule instead of by tuning entry (A/B experiments): "<min M>[:<workgroups to reach by split-K>]"
+_halo = os.environ.get("UPGPT_HALO", "")
+HALO_FORCE = bool(_halo) and _halo != "0"
+HALO_MIN_M = int(_halo.split(":")[0]) if HALO_FORCE else 0
+HALO_WGS = int(_halo.split(":")[1]) if HALO_FORCE and ":" in _halo else 200
 LN_LAUNCH_US = 3.0  # what a separate LayerNorm launch costs inside the replayed forward (class ablation: 3.8)
 
 
@@ -272,12 +308,12 @@ class Program:
         self.attn_flops = 0
         self.n_launch = 0
 
-    def run(self, stream=None, skip=()):
-        """skip: op classes to leave out (ablation timing only: results are garbage)."""
+    def run(self, stream=None, skip=(), skip_idx=()):
+        """skip: op classes / skip_idx: op indices to leave out (ablation timing only: results are garbage)."""
         s = self.ctx._s() if stream is None else stream
-        if skip:
-            for op, cls in zip(self.ops, self.cls):
-                if cls not in skip:
+        if skip or skip_idx:
+            for i, (op, cls) in enumerate(zip(self.ops, self.cls)):
+                if cls not in skip and i not in skip_idx:
                     op(s)
             return
         for op in self.ops:
@@ -302,12 +338,14 @@ class Emitter:
         self.dev = ctx.device
         self.bufs = []
         self.convs = []  # (ConvDesc, shape-signature) of every emitted conv, for autotuning
+        TUNE_CACHE.bind(self.lib)  # (the emitters consult the cache while they lower the network)
 
     def apply_tuning(self, cache=None, tune_missing=False, reps=None):
         """Pins each conv launch to the (tile config, split-K) stored in the tuning cache;
         with tune_missing=True unknown shapes are timed on the device first
         (upk_conv_autotune) and added to the cache.  Returns (#hits, #tuned, #missing)."""
         cache = TUNE_CACHE if cache is None else cache
+        cache.bind(self.lib)
         hits = tuned = missing = 0
         for d, key in self.convs:
             ent = cache.get(key)
@@ -327,7 +365,38 @@ class Emitter:
                 missing += 1
             if ent is not None:
                 d.tune_cfg, d.tune_splitk = int(ent[0]) + 1, int(ent[1])
+            if HALO_FORCE:  # (A/B switch: rule-based halo-patch launches instead of the tuned ones)
+                ch = self._halo_choice(d)
+                if ch is not None:
+                    d.tune_cfg, d.tune_splitk = ch[0] + 1, ch[1]
         return hits, tuned, missing
+
+    def _halo_choice(self, d):
+        """Rule-based (configuration, split-K) of the halo-patch 3x3 family for the launch `d`, or None outside its
+        domain (UPGPT_HALO=<min M>[:<split target>]: experiments and untuned shapes; tuned shapes carry their own
+        entry)."""
+        if d.ksize != 3 or d.stride != 1 or d.flags or d.w_phase or d.ln_colsum or d.vt:
+            return None
+        H, W, B = d.in_h, d.in_w, d.batch
+        M = B * H * W
+        if M < HALO_MIN_M or M % 64 or W < 4 or W > 64 or (H * W) & (H * W - 1) or W & (W - 1):
+            return None
+        names = [self.lib.upk_conv_config_name(i).decode() for i in range(self.lib.upk_conv_num_configs())]
+        cpt = (d.c1 + d.c2) // 32
+        best = None
+        for name, bn in (("hc7p2", 112), ("hc4p4", 64), ("hc8p2", 128)):
+            if name not in names or d.n_pad % bn:
+                continue
+            tiles = (M // 64) * (d.n_pad // bn)
+            sk = 1
+            while tiles * sk < HALO_WGS and (sk + 1) * 2 <= cpt and sk < 18:
+                sk += 1
+            while sk > 1 and (sk - 1) * ((cpt + sk - 1) // sk) >= cpt:  # (every split needs chunks of its own)
+                sk -= 1
+            cost = (tiles * sk + 255) // 256 * (bn + 64) * ((cpt + sk - 1) // sk)  # waves of workgroups x bytes per workgroup
+            if best is None or cost < best[0]:
+                best = (cost, names.index(name), sk)
+        return None if best is None else (best[1], best[2])
 
     def _is_as(self, cfg):
         """Whether configuration `cfg` belongs to the A-stationary family (their second tuning slot is output-column
@@ -583,7 +652,7 @@ class Emitter:
                     continue  # (never split K)
                 key = self.convs[sr[1]][1]
                 e = TUNE_CACHE.get(key) or TUNE_CACHE.get(key[:-3] if key.endswith("_gs") else key + "_gs")
-                if e is None or e[1] != 1:
+                if e is None or (e[1] != 1 and not self._is_as(int(e[0]))):  # (as*: second slot = passes per workgroup)
                     return None
         armed = []
         for act in acts:
