@@ -15,7 +15,7 @@ synth.fill_module_(model); model = model.cuda()
 pl = model.model.diffusion_model.plan(8, 32, 32, 87, 50, "sampler")
 pl.prep.run(); torch.cuda.synchronize()
 ctx = pl.ctx
-names = {0: "c.entry", 1: "c.stage0 ready", 2: "c.stage1 start", 3: "c.loop end", 4: "c.stores done",
+names = {0: "c.entry", 1: "c.stage0 ready", 2: "c.stage1 start", 3: "c.loop end", 4: "c.stores done", 5: "h.reduced", 6: "h.stored",
          8: "l.entry", 9: "l.setup done", 10: "l.prologue issued", 11: "l.stage0 landed", 12: "l.loop end"}
 s = torch.cuda.Stream()
 with torch.cuda.stream(s):

@@ -41,6 +41,7 @@ ctx = pl.ctx
 ncfg = ctx.lib.upk_conv_num_configs()
 names = [ctx.lib.upk_conv_config_name(i).decode() for i in range(ncfg)]
 ONLY = os.environ.get("INSITU_ONLY", "")
+ONLY3 = os.environ.get("INSITU_ONLY3", "")  # e.g. INSITU_ONLY3=hc: only the 3x3 shapes, only the halo-patch family's configurations
 
 
 def replay_ms():
@@ -99,7 +100,14 @@ for key in sorted(groups, key=share, reverse=True):
     d0 = ds[0]
     start = (d0.tune_cfg - 1, d0.tune_splitk) if d0.tune_cfg > 0 else None
     sks = sorted({1, 2, 3, 4, 6, 8, 9} | ({start[1]} if start else set()))
-    if ONLY:  # e.g. INSITU_ONLY=as: only the A-stationary family's configurations (second slot = passes per workgroup)
+    if ONLY3:
+        if d0.ksize != 3:
+            continue
+        cands = [(c, s) for c in range(ncfg) if names[c].startswith(ONLY3) for s in (1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 14)
+                 if feasible(d0, c, s)]
+        if not cands:
+            continue
+    elif ONLY:  # e.g. INSITU_ONLY=as: only the A-stationary family's configurations (second slot = passes per workgroup)
         if d0.ksize != 1:
             continue
         cands = [(c, s) for c in range(ncfg) if names[c].startswith(ONLY) for s in (1, 2, 3, 4, 6, 8, 12, 16)
@@ -160,6 +168,7 @@ ent = dict(TUNE_CACHE.d)
 for key, (start, best, t_old, t_new) in changed.items():
     old = ent.get(key) or ent.get(key[:-3]) or [0, 1, 0.0, 0.0]
     ent[key] = [best[0], best[1], old[2], old[3]]
+ent["__configs__"] = names  # (the indices refer to THIS library's configuration list: TuneCache.bind)
 json.dump(ent, open(out, "w"), indent=0, sort_keys=True)
 json.dump({k: [list(v[0]) if v[0] else None, list(v[1]), v[2], v[3]] for k, v in changed.items()},
           open(out.replace(".json", "_changes.json"), "w"), indent=0, sort_keys=True)

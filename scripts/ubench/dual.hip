@@ -9,6 +9,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/dual scripts/ubench/dual.hip && /tmp/dual
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 #include <algorithm>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -22,7 +23,10 @@ __device__ __forceinline__ void wait_vm() {
 
 // waves [0, NB): register stream of `bkb` KB (shared region, half of the grid each); waves [NB, NB + NA): LDS-DMA of
 // `akb` KB (own region), D instructions in flight per wave.  NT: nontemporal hint on the register stream.
-template <int NB, int NA, int D, bool NT>
+// FRAG: lane -> byte mapping of a 1 KiB weight fragment.  false: lane * 16 (contiguous); true: (lane & 15) * 64 +
+// (lane >> 4) * 16 — the MFMA operand order (row = lane & 15, k group = lane >> 4) read out of a [16 rows][64 B] run,
+// i.e. what astat / mlp / xblock / halo do with the [K/32][n][32] packing: every quarter wave touches 16 different rows
+template <int NB, int NA, int D, bool NT, bool FRAG = false>
 __global__ __launch_bounds__(512) void dual(const char* wsrc, const char* asrc, int bkb, int akb, int row_bytes,
                                             unsigned long long* out, float* sink) {
   __shared__ __attribute__((aligned(16))) char lds[64 * 1024];
@@ -30,7 +34,7 @@ __global__ __launch_bounds__(512) void dual(const char* wsrc, const char* asrc, 
   const unsigned long long t0 = __builtin_readcyclecounter();
   unsigned long long tb = 0, ta = 0;
   if (wave < NB) {
-    const char* base = wsrc + (size_t)(blockIdx.x & 1) * ((size_t)bkb << 10) + lane * 16;
+    const char* base = wsrc + (size_t)(blockIdx.x & 1) * ((size_t)bkb << 10) + (FRAG ? (lane & 15) * 64 + (lane >> 4) * 16 : lane * 16);
     const int nfr = bkb / NB;  // 1 KiB fragments of this wave
     f32x4 ring[D];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(512) void dual(const char* wsrc, const char* asrc, 
   }
 }
 
-template <int NB, int NA, int D, bool NT>
+template <int NB, int NA, int D, bool NT, bool FRAG = false>
 void run(const char* tag, char* w, char* a, char* flush, int bkb, int akb, int row_bytes, unsigned long long* out) {
   std::vector<unsigned long long> h(512);
   double bb = 1e18, ba = 1e18;
@@ -93,7 +97,7 @@ void run(const char* tag, char* w, char* a, char* flush, int bkb, int akb, int r
     hipMemset(flush, rep, (size_t)1 << 30);
     hipMemset(out, 0, 512 * 8);
     hipDeviceSynchronize();
-    hipLaunchKernelGGL((dual<NB, NA, D, NT>), dim3(256), dim3(512), 0, 0, w, a, bkb, akb, row_bytes, out, (float*)nullptr);
+    hipLaunchKernelGGL((dual<NB, NA, D, NT, FRAG>), dim3(256), dim3(512), 0, 0, w, a, bkb, akb, row_bytes, out, (float*)nullptr);
     hipDeviceSynchronize();
     hipMemcpy(h.data(), out, 512 * 8, hipMemcpyDeviceToHost);
     double sb = 0, sa = 0;
@@ -119,6 +123,13 @@ int main() {
   hipMemset(a, 1, (size_t)256 << 20);
   // the 3x3 224 -> 224 conv at 32x32, 64 x 112 tile: 451 KB of weights, 258 KB of im2col rows / 61 KB of patch rows
   const int RB = 448;  // 224 channels fp16
+  run<8, 0, 8, false, false>("weights, 8 waves, lane-contiguous", w, a, flush, 448, 0, RB, out);
+  run<8, 0, 8, false, true>("weights, 8 waves, MFMA-order gather", w, a, flush, 448, 0, RB, out);
+  run<8, 0, 16, false, false>("weights, 8 waves, lane-contiguous", w, a, flush, 448, 0, RB, out);
+  run<8, 0, 16, false, true>("weights, 8 waves, MFMA-order gather", w, a, flush, 448, 0, RB, out);
+  run<4, 0, 16, false, false>("weights, 4 waves, lane-contiguous", w, a, flush, 448, 0, RB, out);
+  run<4, 0, 16, false, true>("weights, 4 waves, MFMA-order gather", w, a, flush, 448, 0, RB, out);
+  if (getenv("DUAL_FRAG_ONLY")) return 0;
   run<4, 0, 8, false>("weights only, 4 waves", w, a, flush, 448, 0, RB, out);
   run<4, 0, 16, false>("weights only, 4 waves", w, a, flush, 448, 0, RB, out);
   run<8, 0, 8, false>("weights only, 8 waves", w, a, flush, 448, 0, RB, out);

@@ -34,6 +34,7 @@ namespace {
 
 constexpr int HC_NW = 8;
 constexpr int HC_MI = 4;
+constexpr int HC_PFN = 4;  // prefetch requests per wave (items rank + k * G): 4 x G items cover the 63-item slice of the 32x32 level
 
 struct HcArgs {
   const f16* x1;
@@ -56,6 +57,8 @@ struct HcArgs {
   int cpt;        // chunks per tap: ch1 + ch2
   int mps, aps;   // 3x3 / appended chunks per K split
   int cp_off;     // byte offset of the GroupNorm-partials scratch behind ring / reduction buffer
+  int tab_off;    // byte offset of the K-item table behind it
+  int pp_magic, pw_magic;  // ceil(65536 / part_pix), ceil(65536 / pw): exact quotients of patch pixel indices (< 256)
   int sh_hw, sh_w;  // log2 of H * W / W (powers of two by construction)
 };
 #define HC_PIN(v) asm volatile("" ::"s"(v))
@@ -80,19 +83,23 @@ struct HcRound {
 template <int NI, int PF>
 __global__ __launch_bounds__(512) void halo_conv_kernel(const HcArgs s, const IgemmArgs a) {
   constexpr int MI = HC_MI, NW = HC_NW, NF = MI * NI;
-  constexpr int G = NF <= 16 ? NF : NF / 2;  // fragments per reduction group (G * 8 KiB of LDS)
-  static_assert(NF % G == 0, "reduction groups");
+  constexpr int KS = 4;             // K slices: wave = (N half) * 4 + (K slice)
+  constexpr int NJ = (NI + 1) / 2;  // column fragments per wave (the second half of an odd NI carries one dead fragment)
+  constexpr int FW = MI * NJ;       // accumulator fragments per wave
   extern __shared__ __attribute__((aligned(16))) f16 smem[];
 
   HC_PIN(s.x1); HC_PIN(s.x2); HC_PIN(s.x3); HC_PIN(s.x4); HC_PIN(s.w); HC_PIN(s.zero); HC_PIN(s.partial);
   HC_PIN(s.ch1); HC_PIN(s.ch2); HC_PIN(s.ch3); HC_PIN(s.ch4); HC_PIN(s.ld1); HC_PIN(s.ld2); HC_PIN(s.ld3); HC_PIN(s.ld4);
   HC_PIN(s.npad); HC_PIN(s.M); HC_PIN(s.H); HC_PIN(s.W); HC_PIN(s.pw); HC_PIN(s.part_pix); HC_PIN(s.hw); HC_PIN(s.npix);
   HC_PIN(s.ngrp); HC_PIN(s.cr); HC_PIN(s.nslot); HC_PIN(s.cpt); HC_PIN(s.mps); HC_PIN(s.aps); HC_PIN(s.cp_off);
-  HC_PIN(s.sh_hw); HC_PIN(s.sh_w);
+  HC_PIN(s.sh_hw); HC_PIN(s.sh_w); HC_PIN(s.tab_off); HC_PIN(s.pp_magic); HC_PIN(s.pw_magic);
+  // the timestep row of the epilogue's row vector: a dependent scalar load in front of the operand loads otherwise
+  const int st0 = (a.rowvec && a.step) ? *a.step : 0;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ks = wave & (KS - 1), nh = wave >> 2;
   const int lg = lane >> 4, lc = lane & 15;
 #ifdef UPK_TIMELINE
   const bool tl = (a.flags & ABL_TIMELINE) && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && blockIdx.z == 0 && wave == 0;
@@ -137,19 +144,25 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const HcArgs s, const Ig
   const HcRound r_first = round_at(g_first, 0, 0);
 
   // ---- patch geometry of this lane
-  // (a) as a DMA lane: patch pixel P = group * 16 + lane / 4 of the groups {wave, wave + 8}, piece (lane & 3) swizzled
+  // (a) as a DMA lane: patch pixel P = group * 16 + lane / 4, piece (lane & 3) swizzled.  Wave w owns group w in every
+  // chunk; the groups >= 8 (the patch of a 32-wide level has 9, of a 64-wide one 13) are shared out chunk by chunk
   const int b0 = m0 >> s.sh_hw;                          // first image of the tile
   const int y0 = (m0 - (b0 << s.sh_hw)) >> s.sh_w;       // first output row inside it (0 when the tile holds whole images)
   const int piece = (lane & 3) ^ (((lane >> 4) & 1) << 1);
+  const int nextra = max(0, s.ngrp - 8);
+  const int xg = nextra > 0 ? 8 + wave % nextra : -1;                       // this wave's extra group ...
+  const int xrank = nextra > 0 ? wave / nextra : 0;                         // ... of which it takes chunks xrank, xrank + xshare, ...
+  const int xshare = nextra > 0 ? (8 - wave % nextra + nextra - 1) / nextra : 1;
   int pix[2];   // linear input pixel (b * H + iy) * W + ix of the lane's patch pixel, or -1 (padding / past the patch)
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    const int P = (wave + 8 * q) * 16 + (lane >> 2);
-    const int part = P / s.part_pix, rem = P - part * s.part_pix;
-    const int py = rem / s.pw, px = rem - py * s.pw;
+    const int grp = q == 0 ? wave : xg;
+    const int P = grp * 16 + (lane >> 2);
+    const int part = (P * s.pp_magic) >> 16, rem = P - part * s.part_pix;
+    const int py = (rem * s.pw_magic) >> 16, px = rem - py * s.pw;
     const int iy = y0 + py - 1, ix = px - 1;
     const int b = b0 + part;
-    const bool ok = P < s.npix && iy >= 0 && iy < s.H && ix >= 0 && ix < s.W && (b << s.sh_hw) < s.M;
+    const bool ok = grp >= 0 && grp < s.ngrp && P < s.npix && iy >= 0 && iy < s.H && ix >= 0 && ix < s.W && (b << s.sh_hw) < s.M;
     pix[q] = ok ? ((b * s.H + iy) << s.sh_w) + ix : -1;
   }
   const f16* zsrc = s.zero + (lane & 3) * 8;
@@ -163,14 +176,15 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const HcArgs s, const Ig
     const int sld = g < b1 ? s.ld1 : (!app ? s.ld2 : (g < b3 ? s.ld3 : s.ld4));
     const int c0 = (g - (g < b1 ? 0 : (!app ? b1 : (g < b3 ? cpt : b3)))) * 32;  // first channel inside the source
     const unsigned dst0 = lds0 + (unsigned)(r.base * s.ngrp) * 1024u;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int grp = wave + 8 * q;
-      if (grp >= s.ngrp) break;  // (wave-uniform)
-      const f16* src = pix[q] >= 0 ? sp + (long)pix[q] * sld + c0 + piece * 8 : zsrc;
-      const int step = pix[q] >= 0 ? 32 : 0;
-      for (int cl = 0; cl < r.n; ++cl)
-        hc_dma16(src + cl * step, dst0 + (unsigned)((cl * s.ngrp + grp) * 1024));
+    if (wave < s.ngrp) {
+      const f16* src = pix[0] >= 0 ? sp + (long)pix[0] * sld + c0 + piece * 8 : zsrc;
+      const int step = pix[0] >= 0 ? 32 : 0;
+      for (int cl = 0; cl < r.n; ++cl) hc_dma16(src + cl * step, dst0 + (unsigned)((cl * s.ngrp + wave) * 1024));
+    }
+    if (xg >= 0) {
+      const f16* src = pix[1] >= 0 ? sp + (long)pix[1] * sld + c0 + piece * 8 : zsrc;
+      const int step = pix[1] >= 0 ? 32 : 0;
+      for (int cl = xrank; cl < r.n; cl += xshare) hc_dma16(src + cl * step, dst0 + (unsigned)((cl * s.ngrp + xg) * 1024));
     }
   };
   // (b) as an MFMA lane: patch pixel of tile pixel t = i * 16 + lc at tap (0, 0)
@@ -201,51 +215,135 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const HcArgs s, const Ig
   }
   STAMP(1);
 
-  // ---- weight ring.  Cursor = the item PF steps ahead of the one being multiplied; its A-side coordinates travel with
-  // the ring slot (sA: LDS byte offset of the chunk, sT: tap pixel offset, sR: round index; sR == kDead: no item)
-  const int kDead = 1 << 20;
-  HcRound cr_ = r_first;  // round of the cursor
-  int c_next = wave;      // local item index of this wave's next item inside cr_
-  const char* const wb = (const char*)s.w + (size_t)n0 * 64u;
+  // ---- the item table: the workgroup's K items in order (round by round; inside a round tap major, channel chunk
+  // minor = the order of the packed weight, so that the workgroups of a launch walk it front to back), one 8-byte entry
+  // each — x = byte offset of the item's weight chunk, y = LDS KiB offset of its patch chunk | tap pixel offset << 8 |
+  // round << 16 (round 0xffff: no item; 4 * (PF + 2) of those close the table).  Walking the rounds per item in the K
+  // loop cost ~250 scalar instructions per 16 MFMAs: a wave issues one instruction per ~4.5 cycles.
+  const int kDead = 0xffff;
+  unsigned* const tab = (unsigned*)((char*)smem + s.tab_off);
   const unsigned kstr = (unsigned)s.npad * 64u;  // bytes per K chunk of the packed weight
-  const unsigned voff = (unsigned)lane * 16u;
-  unsigned jo[NI];  // byte offset of fragment j inside the tile's run (a fragment past n_pad re-reads fragment 0: its outputs are never stored)
-#pragma unroll
-  for (int j = 0; j < NI; ++j) jo[j] = n0 + j * 16 < s.npad ? (unsigned)j * 1024u : 0u;
-  f16x8 ring[PF][NI];
-  unsigned sA[PF];
-  int sT[PF], sR[PF];
-  auto gen = [&](f16x8 (&dstring)[NI], unsigned& oA, int& oT, int& oR) {
-    // move to the round that holds local item c_next
-    int cnt = cr_.n * (cr_.g >= cpt ? 1 : 9);
-    while (cr_.n > 0 && c_next >= cnt) {
-      c_next -= cnt;
-      cr_ = next_round(cr_);
-      cnt = cr_.n * (cr_.g >= cpt ? 1 : 9);
-    }
-    const bool live = cr_.n > 0;
-    const bool app = cr_.g >= cpt;
-    const int cl = live ? (app ? c_next : (c_next * 7282) >> 16) : 0;
-    const int tap = live ? (app ? 4 : c_next - 9 * cl) : 0;
+  auto entry = [&](const HcRound& r, int loc, unsigned& ex, unsigned& ey) {
+    const bool app = r.g >= cpt;
+    const int tap = app ? 4 : (int)(((float)loc + 0.5f) * __builtin_amdgcn_rcpf((float)r.n));
+    const int cl = app ? loc : loc - tap * r.n;
     const int ky = (tap * 43) >> 7, kx = tap - 3 * ky;
-    const int kc = live ? (app ? 9 * cpt + (cr_.g - cpt) + cl : tap * cpt + cr_.g + cl) : 0;
-    const char* sb = wb + (size_t)((unsigned)kc * kstr);
-#pragma unroll
-    for (int j = 0; j < NI; ++j) dstring[j] = *(const f16x8*)(sb + jo[j] + voff);
-    oA = (unsigned)((cr_.base + cl) * s.ngrp) * 1024u;
-    oT = ky * s.pw + kx;
-    oR = live ? cr_.idx : kDead;
-    c_next += NW;
+    const int kc = app ? 9 * cpt + (r.g - cpt) + cl : tap * cpt + r.g + cl;
+    ex = (unsigned)kc * kstr;
+    ey = (unsigned)((r.base + cl) * s.ngrp) | ((unsigned)(ky * s.pw + kx) << 8) | ((unsigned)r.idx << 16);
   };
+  // ---- weight ring: slot u holds the NJ fragments of the item PF steps ahead of the one being multiplied; the item's
+  // A-side coordinates (entry.y) travel with the slot
+  const int jbase = nh * NJ;  // first column fragment of this wave
+  const char* const wb = (const char*)s.w + (size_t)n0 * 64u;
+  unsigned vo[NJ];  // per-lane byte offset of fragment j: element (row lc, k group lg) of its [16][32] fp16 run (a dead
+                    // fragment — past NI or n_pad — re-reads a live one: one instruction stream, products never stored)
 #pragma unroll
-  for (int u = 0; u < PF; ++u) gen(ring[u], sA[u], sT[u], sR[u]);
+  for (int j = 0; j < NJ; ++j) {
+    const int jj = jbase + j;
+    const bool live = jj < NI && n0 + jj * 16 < s.npad;
+    vo[j] = (unsigned)(lc * 64 + lg * 16) + (live ? (unsigned)jj * 1024u : (n0 + jbase * 16 < s.npad ? (unsigned)jbase * 1024u : 0u));
+  }
+  f16x8 ring[PF][NJ];
+  unsigned sI[PF];
+  unsigned last_off = 0;  // weight offset of the last live item requested (items past the end re-request it: a cache hit)
+  // the first PF items of this wave straight from the round structure when round 0 holds them all (the usual case):
+  // their weights are on the way before the table exists
+  const bool direct = r_first.n * (r_first.g >= cpt ? 1 : 9) >= 4 * PF;
+  if (direct) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      unsigned ex, ey;
+      entry(r_first, ks + 4 * u, ex, ey);
+      ex = __builtin_amdgcn_readfirstlane(ex), ey = __builtin_amdgcn_readfirstlane(ey);
+      sI[u] = ey;
+      last_off = ex;
+      const char* sb = wb + ex;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) ring[u][j] = *(const f16x8*)(sb + vo[j]);
+    }
+  }
+  int nitems = 0;
+  {
+    int first = 0;
+    for (HcRound r = r_first; r.n > 0; r = next_round(r)) {
+      const int cnt = r.n * (r.g >= cpt ? 1 : 9);
+      for (int loc = tid; loc < cnt; loc += 512) {
+        unsigned ex, ey;
+        entry(r, loc, ex, ey);
+        tab[2 * (first + loc)] = ex;
+        tab[2 * (first + loc) + 1] = ey;
+      }
+      first += cnt;
+    }
+    if (tid < 4 * (PF + 2)) {
+      tab[2 * (first + tid)] = 0u;
+      tab[2 * (first + tid) + 1] = (unsigned)kDead << 16;
+    }
+    nitems = first;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  // ---- cooperative prefetch of the weight slice into the XCD's L2.  The workgroups that share this (N tile, K split)
+  // on one XCD (tile_map: xm_mi consecutive M tiles; default order: every 8th) run in lockstep and ask for the same
+  // lines at the same time, so each of them waits out the full HBM latency for every line: 64 KB in flight per CU over
+  // ~2 k cycles = 20-25 B/clk.  Here every one of them first requests ITS share of the slice (items rank, rank + G,
+  // ...: one fragment per wave, results dropped): the whole slice is on its way from HBM at once, and the ring's
+  // requests find it in L2.  Placement (workgroup w on XCD w % 8) is assumed for speed only.
+  f32x4 pfx[HC_PFN];
+  {
+    const int G = a.xm_pm ? a.xm_mi : max(1, a.tiles_m >> 3);
+    const int rank = a.xm_pm ? (int)((blockIdx.x >> 3) % (unsigned)a.xm_mi) : (tm >> 3);
+    const unsigned pvo = (unsigned)(min(wave, NI - 1) * 1024 + lane * 16);
+#pragma unroll
+    for (int k = 0; k < HC_PFN; ++k) {
+      const int it = min(rank + k * G, nitems - 1);
+      const unsigned off = __builtin_amdgcn_readfirstlane(tab[2 * it]);
+      pfx[k] = *(const f32x4*)(wb + off + pvo);
+    }
+  }
+  const uint2* const tq = (const uint2*)tab + ks;  // this wave's entries: tq[4 k]
+  if (!direct) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const uint2 e = tq[4 * u];
+      const unsigned ex = __builtin_amdgcn_readfirstlane(e.x), ey = __builtin_amdgcn_readfirstlane(e.y);
+      sI[u] = ey;
+      if ((ey >> 16) != (unsigned)kDead) last_off = ex;
+      const char* sb = wb + last_off;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) ring[u][j] = *(const f16x8*)(sb + vo[j]);
+    }
+  }
+  // ---- operands of the fragments this wave will finish (bias, timestep row, residual): requested now, one memory round
+  // trip under the K loop instead of one in front of the stores
+  const Epi::Plain P(a, st0);
+  float* slab = s.partial ? s.partial + (long)zs * a.M * a.npad : nullptr;
+  Epi::Plain::Row rows[NJ];
+  f32x4 bvs[NJ], rvs[NJ];
+  f16x4 rrs[NJ];
+#pragma unroll
+  for (int q = 0; q < NJ; ++q) {
+    const int fw = ks + KS * q;
+    const int i = fw / NJ, jj = jbase + (fw - i * NJ);
+    const int n = n0 + jj * 16 + lg * 4;
+    rows[q] = P.row(a, jj < NI ? m0 + i * 16 + lc : a.M, a.M);
+    bvs[q] = P.bias4(a, n);
+    rvs[q] = P.rv4(a, rows[q], n);
+    rrs[q] = P.res4(a, rows[q], n);
+  }
+  uint2 enext = tq[4 * PF];  // entry of the next refill, read one step ahead of its use
+  int qn = 4 * (PF + 1);
   STAMP(2);
 
-  f32x4 acc[MI][NI];
+  f32x4 acc[MI][NJ];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  unsigned Pl6[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) Pl6[i] = Pl[i] << 6;
 
   // ---- K loop
   const char* const sm = (const char*)smem;
@@ -261,104 +359,91 @@ __global__ __launch_bounds__(512) void halo_conv_kernel(const HcArgs s, const Ig
     }
     ++have;
   };
+  while (have < 1) avail();  // (round 0: the patch has landed — and with it the prefetch requests, whose values are dropped here)
+#pragma unroll
+  for (int k = 0; k < HC_PFN; ++k) asm volatile("" ::"v"(pfx[k]));
   bool done = false;
 #pragma unroll 1
   while (!done) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-      const int need = sR[u] == kDead ? total_rounds : sR[u] + 1;
+      const int rnd = (int)(sI[u] >> 16);
+      const int need = rnd == kDead ? total_rounds : rnd + 1;
       while (have < need) avail();
-      if (sR[u] == kDead) {
+      if (rnd == kDead) {
         done = true;
         break;
       }
+      // S = byte offset of (patch pixel at this tap, piece 0) inside the LDS; bit 8 of it = bit 2 of the pixel index
+      const unsigned sc = ((sI[u] & 255u) << 10) + (((sI[u] >> 8) & 255u) << 6);
       f16x8 fa[MI];
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
-        const unsigned t = Pl[i] + (unsigned)sT[u];
-        const unsigned ad = sA[u] + (t << 6) + (lg16 ^ ((t & 4u) << 3));
-        fa[i] = *(const f16x8*)(sm + ad);
+        const unsigned S = Pl6[i] + sc;
+        fa[i] = *(const f16x8*)(sm + (S + (lg16 ^ ((S >> 3) & 32u))));
       }
+      // the item PF steps ahead: its fragment j is requested as soon as slot u's fragment j has been multiplied
+      sI[u] = __builtin_amdgcn_readfirstlane(enext.y);
+      if ((sI[u] >> 16) != (unsigned)kDead) last_off = __builtin_amdgcn_readfirstlane(enext.x);
+      const char* sb = wb + last_off;
+      enext = tq[qn];
+      qn += 4;
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+      for (int j = 0; j < NJ; ++j) {
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+        for (int i = 0; i < MI; ++i)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[u][j], fa[i], acc[i][j], 0, 0, 0);
-      gen(ring[u], sA[u], sT[u], sR[u]);
+        ring[u][j] = *(const f16x8*)(sb + vo[j]);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
   STAMP(3);
 
-  // ---- the eight K slices are summed through LDS, G fragments at a time; wave w finishes fragments f0 + w, f0 + w + 8
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (dead refills of the ring: nothing in flight into registers)
+  // ---- the four K slices of each N half are summed through LDS; wave (ks, nh) finishes the fragments ks, ks + 4, ...
+  // of its half
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (the ring's last refills: nothing in flight into registers)
   __builtin_amdgcn_s_barrier();                                 // every wave is out of the patch: the ring is free
-  float* red = (float*)smem;                                    // [8 waves][G fragments][64 lanes][4]
+  float* red = (float*)smem;                                    // [8 waves][FW fragments][64 lanes][4]
   float* cpred = (float*)((char*)smem + s.cp_off);              // [NF][2][16] GroupNorm partials of the finished fragments
-  constexpr int FQ = (G + NW - 1) / NW;                         // fragments a wave finishes per group
-  const Epi::Plain P(a);
-  float* slab = s.partial ? s.partial + (long)zs * a.M * a.npad : nullptr;
 #pragma unroll
-  for (int f0 = 0; f0 < NF; f0 += G) {
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int q = 0; q < G; ++q) {
-      const int f = f0 + q;
-      *(f32x4*)(red + ((wave * G + q) * 64 + lane) * 4) = acc[f / NI][f % NI];
+    for (int j = 0; j < NJ; ++j) *(f32x4*)(red + ((wave * FW + i * NJ + j) * 64 + lane) * 4) = acc[i][j];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  STAMP(5);
+#pragma unroll
+  for (int q = 0; q < NJ; ++q) {
+    const int fw = ks + KS * q;
+    const int i = fw / NJ, jj = jbase + (fw - i * NJ);
+    if (jj >= NI) continue;  // (the dead fragment of an odd NI's second half; wave-uniform)
+    f32x4 v = *(const f32x4*)(red + (((nh * KS + 0) * FW + fw) * 64 + lane) * 4);
+#pragma unroll
+    for (int w = 1; w < KS; ++w) v += *(const f32x4*)(red + (((nh * KS + w) * FW + fw) * 64 + lane) * 4);
+    const int m = m0 + i * 16 + lc;
+    const int n = n0 + jj * 16 + lg * 4;
+    if (slab) {
+      if (n < a.npad && m < a.M) *(f32x4*)(slab + (unsigned)m * (unsigned)a.npad + n) = v;
+      continue;
     }
-    // operands of this wave's fragments (requested before the barrier: one round trip under the LDS exchange)
-    Epi::Plain::Row rows[FQ];
-    f32x4 bvs[FQ], rvs[FQ];
-    f16x4 rrs[FQ];
-    if (!slab) {
+    const f16x4 o = Epi::Plain::put(a, rows[q], n, v + bvs[q] + rvs[q], rrs[q]);
+    if (a.gn_cp) {
+      f32x4 su, sq;
 #pragma unroll
-      for (int q = 0; q < FQ; ++q) {
-        const int fl = wave + NW * q;
-        const int f = f0 + fl;
-        const int i = f / NI, j = f - i * NI;
-        const int n = n0 + j * 16 + lg * 4;
-        rows[q] = P.row(a, fl < G ? m0 + i * 16 + lc : a.M, a.M);
-        bvs[q] = P.bias4(a, n);
-        rvs[q] = P.rv4(a, rows[q], n);
-        rrs[q] = P.res4(a, rows[q], n);
+      for (int k = 0; k < 4; ++k) {
+        const float x = (float)o[k];
+        su[k] = Epi::row_sum16(x);
+        sq[k] = Epi::row_sum16(x * x);
       }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int q = 0; q < FQ; ++q) {
-      const int fl = wave + NW * q;
-      if (fl >= G) continue;  // (wave-uniform)
-      const int f = f0 + fl;
-      const int i = f / NI, j = f - i * NI;
-      f32x4 v = *(const f32x4*)(red + ((0 * G + fl) * 64 + lane) * 4);
-#pragma unroll
-      for (int w = 1; w < NW; ++w) v += *(const f32x4*)(red + ((w * G + fl) * 64 + lane) * 4);
-      const int m = m0 + i * 16 + lc;
-      const int n = n0 + j * 16 + lg * 4;
-      if (slab) {
-        if (n < a.npad && m < a.M) *(f32x4*)(slab + (unsigned)m * (unsigned)a.npad + n) = v;
-        continue;
+      if (lc == 0) {
+        const int f = i * NI + jj;
+        *(f32x4*)(cpred + f * 32 + lg * 4) = su;
+        *(f32x4*)(cpred + f * 32 + 16 + lg * 4) = sq;
       }
-      const f16x4 o = Epi::Plain::put(a, rows[q], n, v + bvs[q] + rvs[q], rrs[q]);
-      if (a.gn_cp) {
-        f32x4 su, sq;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float x = (float)o[k];
-          su[k] = Epi::row_sum16(x);
-          sq[k] = Epi::row_sum16(x * x);
-        }
-        if (lc == 0) {
-          *(f32x4*)(cpred + f * 32 + lg * 4) = su;
-          *(f32x4*)(cpred + f * 32 + 16 + lg * 4) = sq;
-        }
-      }
-    }
-    if (f0 + G < NF) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // (the reduction buffer is rewritten by the next group)
     }
   }
+  STAMP(6);
   if (!slab && a.gn_cp) {  // (workgroup-uniform) the MI row fragments of each column fragment combined, fixed order
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -390,10 +475,10 @@ struct HcCfg {
 };
 #define HCC(NI, PF) {NI, PF, "hc" #NI "p" #PF, halo_conv_kernel<NI, PF>}
 const HcCfg kHc[] = {
-    HCC(7, 2),  // 64 x 112 (the 7 * 32 channel family), 14 KiB of weights in flight per wave
-    HCC(4, 4),  // 64 x 64, 16 KiB in flight
-    HCC(4, 2),  // 64 x 64,  8 KiB in flight (short K ranges per split)
-    HCC(8, 2),  // 64 x 128 (power-of-two channel counts: the upscale UNet)
+    HCC(7, 4),  // 64 x 112 (the 7 * 32 channel family): waves hold 64 x 64 | 64 x 48, 16 KiB of weights in flight per wave
+    HCC(4, 8),  // 64 x 64: waves hold 64 x 32, 16 KiB in flight
+    HCC(4, 4),  // 64 x 64,  8 KiB in flight (short K ranges per split)
+    HCC(8, 4),  // 64 x 128 (power-of-two channel counts: the upscale UNet): waves hold 64 x 64
 };
 constexpr int kNumHc = sizeof(kHc) / sizeof(kHc[0]);
 bool hc_attr_done[kNumHc];
@@ -438,9 +523,8 @@ bool hc_plan(const upk_ctx* ctx, const IgemmArgs& a, int c, int splitk, HcPlan* 
   if (splitk > 1 && (mps < 1 || (splitk - 1) * mps >= cpt)) return false;  // (every split has 3x3 chunks)
   // rounds: the whole K range of a workgroup in one slot when it fits, else two slots of cr chunks
   const int NF = HC_MI * kHc[c].ni;
-  const int Gf = NF <= 16 ? NF : NF / 2;
-  const int red_bytes = HC_NW * Gf * 1024;
-  const int budget = 152 * 1024;
+  const int red_bytes = HC_NW * HC_MI * ((kHc[c].ni + 1) / 2) * 1024;  // [8 waves][4 x NJ fragments][1 KiB]
+  const int budget = 148 * 1024;  // (160 KiB less the GroupNorm scratch and the K-item table)
   const int kchunks = mps + aps;
   int cr, nslot;
   if (kchunks * ngrp * 1024 <= budget) {
@@ -453,12 +537,14 @@ bool hc_plan(const upk_ctx* ctx, const IgemmArgs& a, int c, int splitk, HcPlan* 
   }
   const int ring_bytes = nslot * cr * ngrp * 1024;
   pl->cp_off = ring_bytes > red_bytes ? ring_bytes : red_bytes;
-  pl->lds_bytes = pl->cp_off + NF * 128;
+  pl->tab_off = pl->cp_off + NF * 128;
+  pl->lds_bytes = pl->tab_off + (mps * 9 + aps + 4 * (kHc[c].pf + 2)) * 8;
   if (pl->lds_bytes > 160 * 1024) return false;
   pl->bn = kHc[c].ni * 16;
   pl->splitk = splitk;
   pl->pw = pw, pl->part_pix = part_pix, pl->npix = npix, pl->ngrp = ngrp, pl->cr = cr, pl->nslot = nslot;
   pl->cpt = cpt, pl->mps = mps, pl->aps = aps, pl->sh_hw = shw, pl->sh_w = sw;
+  pl->pp_magic = (65536 + part_pix - 1) / part_pix, pl->pw_magic = (65536 + pw - 1) / pw;
   return true;
 }
 
@@ -471,7 +557,7 @@ int hc_launch(upk_ctx* ctx, const IgemmArgs& a, int c, const HcPlan& pl, dim3 gr
   s.npad = a.npad, s.M = a.M, s.H = a.HS, s.W = a.WS;
   s.pw = pl.pw, s.part_pix = pl.part_pix, s.hw = a.HS * a.WS, s.npix = pl.npix, s.ngrp = pl.ngrp;
   s.cr = pl.cr, s.nslot = pl.nslot, s.cpt = pl.cpt, s.mps = pl.mps, s.aps = pl.aps, s.cp_off = pl.cp_off;
-  s.sh_hw = pl.sh_hw, s.sh_w = pl.sh_w;
+  s.sh_hw = pl.sh_hw, s.sh_w = pl.sh_w, s.tab_off = pl.tab_off, s.pp_magic = pl.pp_magic, s.pw_magic = pl.pw_magic;
   if (!hc_attr_done[c]) {  // (one call per configuration and process: a no-op on current ROCm, kept for runtimes that honour it)
     UPK_HIP(ctx, hipFuncSetAttribute((const void*)kHc[c].fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hc_attr_done[c] = true;

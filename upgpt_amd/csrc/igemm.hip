@@ -1316,7 +1316,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     best = want_cfg;
     best_sk = sk;
   }
-  const bool is_as = want_cfg >= kNumCfgs && !is_bt;
+  const bool is_as = want_cfg >= kNumCfgs && !is_bt && !is_hc;
   if (is_as) {
     if (!astat_plan(ctx, a, want_cfg - kNumCfgs, want_sk, &aspl) || (want_sk > 1 && want_sk > aspl.npass))
       return upk_fail(ctx, UPK_ESHAPE, "conv: A-stationary configuration %s (passes per workgroup %d) does not fit this launch",

@@ -327,14 +327,16 @@ struct Epi {
     const f16* resp;
     unsigned has_b, has_rv, has_res;
     int st, hw;
-    __device__ __forceinline__ Plain(const IgemmArgs& a) {
+    __device__ __forceinline__ Plain(const IgemmArgs& a) : Plain(a, (a.rowvec && a.step) ? *a.step : 0) {}
+    // (st_: the step index read by the caller, e.g. at kernel entry — the load is a dependent round trip here)
+    __device__ __forceinline__ Plain(const IgemmArgs& a, int st_) {
       bias = a.bias ? a.bias : (const float*)a.zero;
       rvp = a.rowvec ? a.rowvec : (const float*)a.zero;
       resp = a.res ? a.res : a.zero;
       has_b = a.bias ? ~0u : 0u;
       has_rv = a.rowvec ? ~0u : 0u;
       has_res = a.res ? ~0u : 0u;
-      st = (a.rowvec && a.step) ? *a.step : 0;
+      st = st_;
       hw = a.Ho * a.Wo;
     }
     __device__ __forceinline__ f32x4 bias4(const IgemmArgs& a, int n) const {
@@ -613,8 +615,8 @@ int bt_launch(upk_ctx* ctx, const IgemmArgs& a, int c, dim3 grid, hipStream_t st
 // halo.hip: the halo-patch 3x3 family (configurations behind the big-tile ones): input patch resident in LDS, weights
 // streamed into registers by eight K-splitting waves; second tuning slot = split-K factor over channel ranges
 struct HcPlan {
-  int bn, splitk, lds_bytes, cp_off;
-  int pw, part_pix, npix, ngrp, cr, nslot, cpt, mps, aps, sh_hw, sh_w;
+  int bn, splitk, lds_bytes, cp_off, tab_off;
+  int pw, part_pix, npix, ngrp, cr, nslot, cpt, mps, aps, sh_hw, sh_w, pp_magic, pw_magic;
 };
 int hc_num_configs();
 const char* hc_config_name(int c);

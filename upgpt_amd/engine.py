@@ -118,7 +118,7 @@ HBLOCK_GN = os.environ.get("UPGPT_HBLOCK_GN", "1") == "1"  # SpatialTransformer.
 _halo = os.environ.get("UPGPT_HALO", "")
 HALO_FORCE = bool(_halo) and _halo != "0"
 HALO_MIN_M = int(_halo.split(":")[0]) if HALO_FORCE else 0
-HALO_WGS = int(_halo.split(":")[1]) if HALO_FORCE and ":" in _halo else 200
+HALO_WGS = int(_halo.split(":")[1]) if HALO_FORCE and ":" in _halo else 256
 LN_LAUNCH_US = 3.0  # what a separate LayerNorm launch costs inside the replayed forward (class ablation: 3.8)
 
 
@@ -383,17 +383,18 @@ class Emitter:
             return None
         names = [self.lib.upk_conv_config_name(i).decode() for i in range(self.lib.upk_conv_num_configs())]
         cpt = (d.c1 + d.c2) // 32
+        cus = self.ctx.num_cus
         best = None
-        for name, bn in (("hc7p2", 112), ("hc4p4", 64), ("hc8p2", 128)):
+        for name, bn in (("hc7p4", 112), ("hc4p8", 64), ("hc8p4", 128)):
             if name not in names or d.n_pad % bn:
                 continue
             tiles = (M // 64) * (d.n_pad // bn)
-            sk = 1
-            while tiles * sk < HALO_WGS and (sk + 1) * 2 <= cpt and sk < 18:
-                sk += 1
+            sk = max(1, min(HALO_WGS // tiles, cpt // 2, 18))  # one workgroup per CU: as many K splits as fit the chip
             while sk > 1 and (sk - 1) * ((cpt + sk - 1) // sk) >= cpt:  # (every split needs chunks of its own)
                 sk -= 1
-            cost = (tiles * sk + 255) // 256 * (bn + 64) * ((cpt + sk - 1) // sk)  # waves of workgroups x bytes per workgroup
+            # us: waves of workgroups x (fixed + the weight stream of one workgroup at ~96 KB/us) + the reduce pass
+            kb = bn * 9 * 32 * ((cpt + sk - 1) // sk) * 2 / 1024.0
+            cost = -(-tiles * sk // cus) * (5.0 + kb / 96.0) + (6.0 if sk > 1 else 0.0)
             if best is None or cost < best[0]:
                 best = (cost, names.index(name), sk)
         return None if best is None else (best[1], best[2])
