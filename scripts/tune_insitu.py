@@ -41,7 +41,7 @@ ctx = pl.ctx
 ncfg = ctx.lib.upk_conv_num_configs()
 names = [ctx.lib.upk_conv_config_name(i).decode() for i in range(ncfg)]
 ONLY = os.environ.get("INSITU_ONLY", "")
-ONLY3 = os.environ.get("INSITU_ONLY3", "")  # e.g. INSITU_ONLY3=hc: only the 3x3 shapes, only the halo-patch family's configurations
+ONLY3 = os.environ.get("INSITU_ONLY3", "")  # only the 3x3 shapes, only the configurations whose names start with this prefix
 
 
 def replay_ms():

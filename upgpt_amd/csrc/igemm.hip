@@ -299,6 +299,19 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
   constexpr int DUMP = 512;              // 1 KiB dump row group for balance DMAs
 
   __shared__ __attribute__((aligned(16))) f16 smem[NBUF * STAGE + DUMP];
+  // Shared epilogue of the M x N-split configurations (plain epilogue, no slabs): an MFMA wave keeps the first NJ0
+  // column fragments of its register tile and hands the other NJ1 to the loader wave beside it through LDS — operand
+  // round trip, stores and GroupNorm partials of a tile run on eight waves instead of four (in-kernel stamps of the
+  // 3x3 224 -> 224 conv: epilogue 10.5-13.4 k of 43.7 k cycles on four waves; the K-split kernels' fragment exchange
+  // already lets every wave finish any fragment)
+  constexpr int NJ0 = (NI + 1) / 2, NJ1 = NI - NJ0;
+  constexpr int HAND_OFF = 8192;  // bytes: behind tile_plain_cp's scratch (WM * WN * NI * 32 floats <= 4 KiB)
+#ifdef UPK_KSPLIT_EPI4
+  constexpr bool SHARE = false;
+#else
+  constexpr bool SHARE = !KSPLIT && NJ1 >= 1 && HAND_OFF + 4 * MI * NJ1 * 1024 <= (NBUF * STAGE + DUMP) * 2;
+#endif
+  static_assert(WM * WN * NI * 32 * 4 <= HAND_OFF, "tile_plain_cp scratch");
 
   if ABL_ON(ABL_EMPTY) return;
   const bool tl = ABL_ON(ABL_TIMELINE) && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && blockIdx.z == 0;
@@ -475,7 +488,32 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
       __builtin_amdgcn_s_barrier();
     }
     if (lw == 0) STAMP(12);
+    // K-split configurations: the loader waves stay for the epilogue — the four K slices meet in LDS anyway, and eight
+    // waves finishing NF / 8 fragments each (operand round trip, stores, GroupNorm partials) are through in about half
+    // the time four take (in-kernel stamps: epilogue 10-13 k of a 44 k-cycle launch)
+#ifdef UPK_KSPLIT_EPI4  // (A/B builds: the four MFMA waves alone)
     return;
+#else
+    if constexpr (!KSPLIT) {
+      if constexpr (SHARE) {
+        if (Epi::plain(a) && !a.partial && !a.lnr_out) {  // (workgroup-uniform: the MFMA waves take the same branch)
+          const int pwm = lw / WN, pwn = lw - pwm * WN;   // the MFMA wave beside this one
+          const int lg = lane >> 4, lc = lane & 15;
+          __builtin_amdgcn_s_barrier();                   // its NJ1 fragments are in LDS
+          const float* hand = (const float*)((const char*)smem + HAND_OFF) + lw * (MI * NJ1) * 256;
+          f32x4 acc2[MI][NJ1];
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ1; ++j) acc2[i][j] = *(const f32x4*)(hand + ((i * NJ1 + j) * 64 + lane) * 4);
+          const int mw = m0 + pwm * (MI * 16), nw = n0 + pwn * (NI * 16) + NJ0 * 16;
+          if (a.gn_cp) Epi::tile_plain_cp<MI, NJ1, WM, WN, NI>(a, m0, mw, nw, lc, lg, acc2, pwm, pwn, (float*)smem, a.M, NJ0);
+          else Epi::tile_plain<MI, NJ1>(a, mw, nw, lc, lg, acc2, a.M);
+        }
+      }
+      return;
+    }
+#endif
   }
 
   // ================================ consumers ================================
@@ -500,9 +538,9 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
 #pragma unroll
   for (int i = 0; i < MI; ++i) ln_s1[i] = ln_s2[i] = 0.f;
 
-  __builtin_amdgcn_s_barrier();  // stage 0 is in LDS
+  if (wave < 4) __builtin_amdgcn_s_barrier();  // stage 0 is in LDS
   if (wave == 0) STAMP(1);
-  for (int t = 0; t < nstages; ++t) {
+  for (int t = 0; t < (wave < 4 ? nstages : 0); ++t) {
     if (wave == 0 && t == 1) STAMP(2);
     const f16* slot = smem + (t % NBUF) * STAGE;
 #pragma unroll
@@ -553,11 +591,18 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
     constexpr int NF = MI * NI;
     static_assert(NF * 4096 <= NBUF * STAGE * 2, "reduction buffer must fit in the ring");
     float* red = (float*)smem;  // [4 waves][NF fragments][64 lanes][4]
+    if (wave < 4) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < NI; ++j) *(f32x4*)(red + ((wave * NF + i * NI + j) * 64 + lane) * 4) = acc[i][j];
-    __syncthreads();  // MFMA waves only: the loader waves have already ended
+        for (int j = 0; j < NI; ++j) *(f32x4*)(red + ((wave * NF + i * NI + j) * 64 + lane) * 4) = acc[i][j];
+    }
+    __syncthreads();  // (all eight waves: the loaders come here from their last stage)
+#ifdef UPK_KSPLIT_EPI4
+    constexpr int EW = 4;
+#else
+    constexpr int EW = 8;  // waves in the epilogue
+#endif
     if ABL_ON(ABL_NOEPI) return;
     auto frag_sum = [&](int f) {
       f32x4 v = *(const f32x4*)(red + ((0 * NF + f) * 64 + lane) * 4);
@@ -567,7 +612,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
     };
     float* slab = a.partial ? a.partial + ((long)zs * (a.ph_on ? 4 : 1) + ph) * a.M * a.npad : nullptr;
     if (slab) {
-      for (int f = wave; f < NF; f += 4) {  // fragment f = (i, j) is finished by wave f % 4
+      for (int f = wave; f < NF; f += EW) {  // fragment f = (i, j) is finished by wave f % 8
         const int i = f / NI, j = f - i * NI;
         const int m = m0 + i * 16 + lc;
         const int n = n0 + j * 16 + lg * 4;
@@ -575,8 +620,8 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
       }
       return;
     }
-    // this wave's fragments f = wave + 4q
-    constexpr int FW = (NF + 3) / 4;
+    // this wave's fragments f = wave + 8q
+    constexpr int FW = (NF + EW - 1) / EW;
     if (Epi::plain(a)) {  // straight-line common case (see Epi::Plain)
       const Epi::Plain P(a);
       Epi::Plain::Row rows[FW];
@@ -584,7 +629,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
       f16x4 rrs[FW];
 #pragma unroll
       for (int q = 0; q < FW; ++q) {
-        const int f = wave + 4 * q;
+        const int f = wave + EW * q;
         const int i = f / NI, j = f - i * NI;
         const int n = n0 + j * 16 + lg * 4;
         rows[q] = P.row(a, f < NF ? m0 + i * 16 + lc : a.M, a.M);
@@ -598,7 +643,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
       float* cpred = red + NF * 1024;  // [NF][2][16]
 #pragma unroll
       for (int q = 0; q < FW; ++q) {
-        const int f = wave + 4 * q;
+        const int f = wave + EW * q;
         if (f >= NF) continue;
         const int j = f - (f / NI) * NI;
         f32x4 fs = frag_sum(f);
@@ -656,7 +701,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
         float* dst = a.gn_cp + (long)((b * a.gn_nblk + blk) * 2) * a.npad;
         if (lane < 32) {
           const int which = lane >> 4, col = lane & 15;
-          for (int j = wave; j < NI; j += 4) {
+          for (int j = wave; j < NI; j += EW) {
             float t = 0.f;
 #pragma unroll
             for (int i = 0; i < MI; ++i) t += cpred[(i * NI + j) * 32 + which * 16 + col];
@@ -673,7 +718,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
     f32x4 bvs[FW], bgs[FW];
 #pragma unroll
     for (int q = 0; q < FW; ++q) {
-      const int f = wave + 4 * q;
+      const int f = wave + EW * q;
       const int i = f / NI, j = f - i * NI;
       const int n = n0 + j * 16 + lg * 4;
       const bool live = f < NF && !(geglu && (j & 2));
@@ -684,7 +729,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
     }
 #pragma unroll
     for (int q = 0; q < FW; ++q) {
-      const int f = wave + 4 * q;
+      const int f = wave + EW * q;
       if (f >= NF) continue;
       const int i = f / NI, j = f - i * NI;
       const int n = n0 + j * 16 + lg * 4;
@@ -754,6 +799,30 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
       }
     }
     return;
+  }
+  if constexpr (SHARE) {
+    if (Epi::plain(a) && !a.lnr_out) {  // (the loader beside this wave finishes fragments NJ0 .. NI - 1)
+      float* hand = (float*)((char*)smem + HAND_OFF) + wave * (MI * NJ1) * 256;
+      f32x4 acc1[MI][NJ0];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          if (j < NJ0) acc1[i][j] = acc[i][j];
+          else *(f32x4*)(hand + ((i * NJ1 + (j - NJ0)) * 64 + lane) * 4) = acc[i][j];
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (a.gn_cp) Epi::tile_plain_cp<MI, NJ0, WM, WN, NI>(a, m0, mw, nw, lc, lg, acc1, wm, wn, (float*)smem, a.M, 0);
+      else Epi::tile_plain<MI, NJ0>(a, mw, nw, lc, lg, acc1, a.M);
+#ifdef UPK_TIMELINE
+      if (wave == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(4);
+      }
+#endif
+      return;
+    }
   }
   Epi::tile<MI, NI, WM, WN>(a, m0, mw, nw, lc, lg, acc, wm, wn, (float*)smem, a.M);
 #ifdef UPK_TIMELINE
@@ -1131,11 +1200,8 @@ double estimate(const CfgInfo& c, int M, int npad, int nchunks, int splitk, int 
 // configurations kNumCfgs .. kNumCfgs + astat_num_configs() - 1 are the A-stationary family (astat.hip); for those the
 // "split-K" slot of the tuning pair means output-column passes per workgroup (0 = fill the chip once)
 // ... and behind those the big-tile family (bigtile.hip); its second slot is a split-K factor like the first families'
-// ... and behind those the halo-patch 3x3 family (halo.hip); second slot = split-K factor over channel ranges
-extern "C" int upk_conv_num_configs(void) { return kNumCfgs + astat_num_configs() + bt_num_configs() + hc_num_configs(); }
+extern "C" int upk_conv_num_configs(void) { return kNumCfgs + astat_num_configs() + bt_num_configs(); }
 extern "C" const char* upk_conv_config_name(int cfg) {
-  if (cfg >= kNumCfgs + astat_num_configs() + bt_num_configs())
-    return hc_config_name(cfg - kNumCfgs - astat_num_configs() - bt_num_configs());
   if (cfg >= kNumCfgs + astat_num_configs()) return bt_config_name(cfg - kNumCfgs - astat_num_configs());
   if (cfg >= kNumCfgs) return astat_config_name(cfg - kNumCfgs);
   return (cfg >= 0 && cfg < kNumCfgs) ? kCfgs[cfg].name : "?";
@@ -1293,18 +1359,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   AsPlan aspl;
   const int bt0 = kNumCfgs + astat_num_configs();
   const bool bt_able = !a.x3 && !(a.ln_u && !a.lnr_in);  // (no appended segment, no fragment-side LayerNorm fold)
-  const int hc0 = bt0 + bt_num_configs();
-  const bool is_hc = want_cfg >= hc0;
-  HcPlan hpl;
-  if (is_hc) {
-    const int sk = want_sk > 0 ? want_sk : 1;
-    if (!hc_plan(ctx, a, want_cfg - hc0, sk, &hpl) || (sk > 1 && slab * sk > ctx->ws_bytes))
-      return upk_fail(ctx, UPK_ESHAPE, "conv: halo-patch configuration %s (split-K %d) does not fit this launch",
-                      hc_config_name(want_cfg - hc0), sk);
-    best = want_cfg;
-    best_sk = sk;
-  }
-  bool is_bt = want_cfg >= bt0 && !is_hc;
+  bool is_bt = want_cfg >= bt0;
   int bt_bm = 0, bt_bn = 0, bt_occ = 1, bt_mi = 0, bt_ni = 0, bt_wn = 1;
   if (is_bt) {
     bt_tile(want_cfg - bt0, &bt_bm, &bt_bn, &bt_occ, &bt_mi, &bt_ni, &bt_wn);
@@ -1316,7 +1371,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     best = want_cfg;
     best_sk = sk;
   }
-  const bool is_as = want_cfg >= kNumCfgs && !is_bt && !is_hc;
+  const bool is_as = want_cfg >= kNumCfgs && !is_bt;
   if (is_as) {
     if (!astat_plan(ctx, a, want_cfg - kNumCfgs, want_sk, &aspl) || (want_sk > 1 && want_sk > aspl.npass))
       return upk_fail(ctx, UPK_ESHAPE, "conv: A-stationary configuration %s (passes per workgroup %d) does not fit this launch",
@@ -1324,7 +1379,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     best = want_cfg;
     best_sk = 1;
   }
-  for (int c = 0; c < kNumCfgs && !is_as && !is_bt && !is_hc; ++c) {
+  for (int c = 0; c < kNumCfgs && !is_as && !is_bt; ++c) {
     if (want_cfg >= 0 && c != want_cfg) continue;
     // folded LayerNorm: row statistics come from the M x N-split wave-specialised kernels, whole K in one block
     if (a.ln_u && !a.lnr_in && !kCfgs[c].fn_ln) continue;
@@ -1367,13 +1422,13 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
                       slab * want_sk, ctx->ws_bytes);
     return upk_fail(ctx, UPK_ESHAPE, "conv: no kernel configuration fits (geglu=%d)", (int)geglu);
   }
-  const CfgInfo& c = kCfgs[(is_as || is_bt || is_hc) ? 0 : best];  // (not used by the other families beyond this block)
-  const int BM = is_hc ? 64 : (is_bt ? bt_bm : (is_as ? aspl.bm : c.mi * 16 * c.wm));
-  const int BN = is_hc ? hpl.bn : (is_bt ? bt_bn : (is_as ? aspl.pw * aspl.ppw : c.ni * 16 * c.wn));
+  const CfgInfo& c = kCfgs[(is_as || is_bt) ? 0 : best];  // (not used by the A-stationary / big-tile families beyond this block)
+  const int BM = is_bt ? bt_bm : (is_as ? aspl.bm : c.mi * 16 * c.wm);
+  const int BN = is_bt ? bt_bn : (is_as ? aspl.pw * aspl.ppw : c.ni * 16 * c.wn);
   a.tiles_m = cdiv(a.M, BM);
   a.tiles_n = is_as ? aspl.tiles_n : cdiv(a.npad, BN);
   a.chunks_per_split = cdiv(a.nchunks, best_sk);
-  const int zdim = is_hc ? hpl.splitk : cdiv(a.nchunks, a.chunks_per_split);  // (halo-patch: channel ranges, all non-empty)
+  const int zdim = cdiv(a.nchunks, a.chunks_per_split);
   a.partial = (zdim > 1) ? (float*)ctx->ws : nullptr;
   // GroupNorm partials from the reduce pass (see igemm_reduce_gn_kernel)
   // ... or the whole GroupNorm from the reduce pass (igemm_reduce_gnapply_kernel)
@@ -1409,7 +1464,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     a.gn_hw = hw_out;
   }
   // LayerNorm row sums of the output for the consumer GEMM (Epi::tile_plain_lnr / the K-split kernels' epilogue)
-  if (d->ln_rows_out && !is_hc && !a.ph_on && zdim == 1 && Epi::plain(a) && !gn_cp && (is_as || is_bt || c.wm * c.wn > 1 || c.nbuf > 0)) {
+  if (d->ln_rows_out && !a.ph_on && zdim == 1 && Epi::plain(a) && !gn_cp && (is_as || is_bt || c.wm * c.wn > 1 || c.nbuf > 0)) {
     // (K-split kernels: one slot per N tile; A-stationary: one per 16 * NI columns of its single pass, else none)
     const int slots = is_as ? (aspl.npass == 1 ? cdiv(a.npad, astat_config_ni(best - kNumCfgs) * 16) : 99)
                             : a.tiles_n * (is_bt ? bt_wn : c.wn);
@@ -1481,8 +1536,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   }
   if (is_as) return astat_launch(ctx, a, best - kNumCfgs, aspl, grid, stream);
   int rc;
-  if (is_hc) rc = hc_launch(ctx, a, best - hc0, hpl, grid, stream);
-  else if (is_bt) rc = bt_launch(ctx, a, best - bt0, grid, stream);
+  if (is_bt) rc = bt_launch(ctx, a, best - bt0, grid, stream);
   else {
   hipLaunchKernelGGL((a.ln_u && !a.lnr_in) ? c.fn_ln : (a.x3 ? c.fn_app : c.fn), grid, dim3(c.nbuf ? 512 : c.wm * c.wn * 64), 0, stream, a);
   rc = upk_check_launch(ctx, "igemm");

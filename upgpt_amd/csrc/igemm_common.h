@@ -449,10 +449,12 @@ struct Epi {
   }
 
   // (separate from tile_plain: the extra accumulators and the workgroup barrier must not weigh on every launch)
-  template <int MI, int NI, int WM, int WN>
+  // NIT / jo: the NI fragments are columns [jo, jo + NI) of a wave column that is NIT fragments wide (a register tile
+  // finished by two waves, igemm_ws_kernel's shared epilogue): `red` is indexed by the position in the whole column
+  template <int MI, int NI, int WM, int WN, int NIT = NI>
   static __device__ __forceinline__ void tile_plain_cp(const IgemmArgs& a, int m0, int mw, int nw, int lc, int lg,
                                                        const f32x4 (&acc)[MI][NI], int wm, int wn, float* red,
-                                                       int mlim) {
+                                                       int mlim, int jo = 0) {
     const Plain P(a);
     constexpr bool cp = true;
     f32x4 bv[NI];
@@ -493,7 +495,7 @@ struct Epi {
         cq[j][k] = row_sum16(cq[j][k]);
       }
     // red[(wm * WN + wn)][j][which][lg * 4 + k]
-    float* mine = red + ((wm * WN + wn) * NI) * 32 + lg * 4;
+    float* mine = red + ((wm * WN + wn) * NIT + jo) * 32 + lg * 4;
     if (lc == 0) {
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
@@ -513,8 +515,8 @@ struct Epi {
         f32x4 su = {0.f, 0.f, 0.f, 0.f}, sq = su;
 #pragma unroll
         for (int w = 0; w < WM; ++w) {
-          su += *(const f32x4*)(red + ((w * WN + wn) * NI + j) * 32 + lg * 4);
-          sq += *(const f32x4*)(red + ((w * WN + wn) * NI + j) * 32 + 16 + lg * 4);
+          su += *(const f32x4*)(red + ((w * WN + wn) * NIT + jo + j) * 32 + lg * 4);
+          sq += *(const f32x4*)(red + ((w * WN + wn) * NIT + jo + j) * 32 + 16 + lg * 4);
         }
         *(f32x4*)(dst + n) = su;
         *(f32x4*)(dst + a.npad + n) = sq;
@@ -611,17 +613,5 @@ void bt_tile(int c, int* bm, int* bn, int* occ, int* mi, int* ni, int* wn);
 bool bt_full_epilogue(int c);  // the configuration also exists with the general epilogue (Epi::tile)
 int bt_launch(upk_ctx* ctx, const IgemmArgs& a, int c, dim3 grid, hipStream_t stream);
 
-
-// halo.hip: the halo-patch 3x3 family (configurations behind the big-tile ones): input patch resident in LDS, weights
-// streamed into registers by eight K-splitting waves; second tuning slot = split-K factor over channel ranges
-struct HcPlan {
-  int bn, splitk, lds_bytes, cp_off, tab_off;
-  int pw, part_pix, npix, ngrp, cr, nslot, cpt, mps, aps, sh_hw, sh_w, pp_magic, pw_magic;
-};
-int hc_num_configs();
-const char* hc_config_name(int c);
-int hc_config_bn(int c);
-bool hc_plan(const upk_ctx* ctx, const IgemmArgs& a, int c, int splitk, HcPlan* pl);
-int hc_launch(upk_ctx* ctx, const IgemmArgs& a, int c, const HcPlan& pl, dim3 grid, hipStream_t stream);
 
 }  // namespace upkd

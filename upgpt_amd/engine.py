@@ -114,11 +114,6 @@ XB_ROWS = int(os.environ.get("UPGPT_XB_ROWS", "0"))  # rows per workgroup (16 / 
 # fused head of a SpatialTransformer (csrc/xblock.hip hblock_kernel: proj_in -> norm1 -> q | k | v, one launch instead of two)
 HBLOCK = os.environ.get("UPGPT_HBLOCK", "auto")
 HBLOCK_GN = os.environ.get("UPGPT_HBLOCK_GN", "1") == "1"  # SpatialTransformer.norm applied on the tile inside that launch
-# halo-patch 3x3 family by rule instead of by tuning entry (A/B experiments): "<min M>[:<workgroups to reach by split-K>]"
-_halo = os.environ.get("UPGPT_HALO", "")
-HALO_FORCE = bool(_halo) and _halo != "0"
-HALO_MIN_M = int(_halo.split(":")[0]) if HALO_FORCE else 0
-HALO_WGS = int(_halo.split(":")[1]) if HALO_FORCE and ":" in _halo else 256
 LN_LAUNCH_US = 3.0  # what a separate LayerNorm launch costs inside the replayed forward (class ablation: 3.8)
 
 
@@ -365,39 +360,7 @@ class Emitter:
                 missing += 1
             if ent is not None:
                 d.tune_cfg, d.tune_splitk = int(ent[0]) + 1, int(ent[1])
-            if HALO_FORCE:  # (A/B switch: rule-based halo-patch launches instead of the tuned ones)
-                ch = self._halo_choice(d)
-                if ch is not None:
-                    d.tune_cfg, d.tune_splitk = ch[0] + 1, ch[1]
         return hits, tuned, missing
-
-    def _halo_choice(self, d):
-        """Rule-based (configuration, split-K) of the halo-patch 3x3 family for the launch `d`, or None outside its
-        domain (UPGPT_HALO=<min M>[:<split target>]: experiments and untuned shapes; tuned shapes carry their own
-        entry)."""
-        if d.ksize != 3 or d.stride != 1 or d.flags or d.w_phase or d.ln_colsum or d.vt:
-            return None
-        H, W, B = d.in_h, d.in_w, d.batch
-        M = B * H * W
-        if M < HALO_MIN_M or M % 64 or W < 4 or W > 64 or (H * W) & (H * W - 1) or W & (W - 1):
-            return None
-        names = [self.lib.upk_conv_config_name(i).decode() for i in range(self.lib.upk_conv_num_configs())]
-        cpt = (d.c1 + d.c2) // 32
-        cus = self.ctx.num_cus
-        best = None
-        for name, bn in (("hc7p4", 112), ("hc4p8", 64), ("hc8p4", 128)):
-            if name not in names or d.n_pad % bn:
-                continue
-            tiles = (M // 64) * (d.n_pad // bn)
-            sk = max(1, min(HALO_WGS // tiles, cpt // 2, 18))  # one workgroup per CU: as many K splits as fit the chip
-            while sk > 1 and (sk - 1) * ((cpt + sk - 1) // sk) >= cpt:  # (every split needs chunks of its own)
-                sk -= 1
-            # us: waves of workgroups x (fixed + the weight stream of one workgroup at ~96 KB/us) + the reduce pass
-            kb = bn * 9 * 32 * ((cpt + sk - 1) // sk) * 2 / 1024.0
-            cost = -(-tiles * sk // cus) * (5.0 + kb / 96.0) + (6.0 if sk > 1 else 0.0)
-            if best is None or cost < best[0]:
-                best = (cost, names.index(name), sk)
-        return None if best is None else (best[1], best[2])
 
     def _is_as(self, cfg):
         """Whether configuration `cfg` belongs to the A-stationary family (their second tuning slot is output-column
