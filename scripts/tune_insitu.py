@@ -41,6 +41,7 @@ ctx = pl.ctx
 ncfg = ctx.lib.upk_conv_num_configs()
 names = [ctx.lib.upk_conv_config_name(i).decode() for i in range(ncfg)]
 ONLY = os.environ.get("INSITU_ONLY", "")
+KEYSUB = os.environ.get("INSITU_KEYS", "")  # only the shapes whose key contains this substring
 ONLY3 = os.environ.get("INSITU_ONLY3", "")  # only the 3x3 shapes, only the configurations whose names start with this prefix
 
 
@@ -96,6 +97,8 @@ def share(key):
 changed = {}
 cur = base
 for key in sorted(groups, key=share, reverse=True):
+    if KEYSUB and KEYSUB not in key:
+        continue
     ds = groups[key]
     d0 = ds[0]
     start = (d0.tune_cfg - 1, d0.tune_splitk) if d0.tune_cfg > 0 else None

@@ -24,6 +24,17 @@ namespace {
 using namespace upkd;
 
 
+// fp32 split-K slab store.  UPK_SC1_SLAB: write-through (sc1) — the 4-17 MB of partials a split launch leaves are then
+// already on their way to memory when the kernel ends instead of being written back at the boundary
+// (MI355X_MICROARCH.md publish-large / boundary: + B / 6 TB/s behind B dirty bytes)
+__device__ __forceinline__ void slab_store(float* p, f32x4 v) {
+#ifdef UPK_SC1_SLAB
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#else
+  *(f32x4*)p = v;
+#endif
+}
+
 // KS = K-chunks (of 32) staged per barrier.  UNet launches have only 1-4 workgroups per CU,
 // so latency must be hidden INSIDE a workgroup: KS chunks of global loads are in flight
 // at once and KS*MI*NI MFMAs run between two barriers.
@@ -244,7 +255,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const int n = nw + j * 16 + lg * 4;
-        if (n < a.npad) *(f32x4*)(slab + roff + n) = acc[i][j];
+        if (n < a.npad) slab_store(slab + roff + n, acc[i][j]);
       }
     }
     return;
@@ -419,6 +430,9 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
       bp[i] = a.w + (long)ph * a.ph_wstride + ((long)kc0 * a.npad + n0 + row) * 32 + chd * 8;
     }
     const long wstep = (long)a.npad * 32;
+#ifdef UPK_NT_W
+    const bool w_nt = a.partial != nullptr && a.tiles_m <= 4;
+#endif
 
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
@@ -441,6 +455,12 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
           const int rg = lw + 4 * i;
           const f16* src = (live && b_ok[i]) ? bp[i] : zsrc;
           f16* dst = (rg < BG) ? base + (s * ROWS + BM + rg * 16) * 32 : smem + NBUF * STAGE;
+#ifdef UPK_NT_W
+          // split-K launches (the 8x8 / 4x4 levels): a weight line is read by the one or two workgroups of its K slice,
+          // once — nontemporal: it does not displace the activations in L2 (MI355X_MICROARCH.md nt-weights)
+          if (w_nt) __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)dst, 16, 0, 2);
+          else
+#endif
           __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)dst, 16, 0, 0);
           bp[i] += wstep;
         }
@@ -616,7 +636,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
         const int i = f / NI, j = f - i * NI;
         const int m = m0 + i * 16 + lc;
         const int n = n0 + j * 16 + lg * 4;
-        if (n < a.npad && m < a.M) *(f32x4*)(slab + (unsigned)m * (unsigned)a.npad + n) = frag_sum(f);
+        if (n < a.npad && m < a.M) slab_store(slab + (unsigned)m * (unsigned)a.npad + n, frag_sum(f));
       }
       return;
     }
@@ -795,7 +815,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const int n = nw + j * 16 + lg * 4;
-        if (n < a.npad) *(f32x4*)(slab + roff + n) = acc[i][j];
+        if (n < a.npad) slab_store(slab + roff + n, acc[i][j]);
       }
     }
     return;
