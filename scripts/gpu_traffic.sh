@@ -22,7 +22,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 L = raw["FETCH_SIZE"]["launches"]
 fetch, write = raw["FETCH_SIZE"]["kb_igemm"] / L, raw["WRITE_SIZE"]["kb_igemm"] / L
 print(json.dumps({
-    "round": 3, "commit": sys.argv[2],
+    "round": 4, "commit": sys.argv[2],
     "kernel_sources_sha256": open(__import__("os").environ["GRAFT_REPO_ROOT"] + "/upgpt_amd/libupk.so.sha256").read().strip(),
     "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python scripts/fwd_replay.py 32 32 %d (scripts/gpu_traffic.sh)" % N,
     "kernel_class": "igemm_ws_kernel<*> + igemm_kernel<*> + igemm_as_kernel<*> + mlp_kernel<*> + hblock_kernel<*> + xblock_kernel<*> + igemm_reduce[_gn|_gnapply]_kernel; per conv/GEMM launch incl. its reduce pass",

@@ -24,15 +24,11 @@ namespace {
 using namespace upkd;
 
 
-// fp32 split-K slab store.  UPK_SC1_SLAB: write-through (sc1) — the 4-17 MB of partials a split launch leaves are then
-// already on their way to memory when the kernel ends instead of being written back at the boundary
-// (MI355X_MICROARCH.md publish-large / boundary: + B / 6 TB/s behind B dirty bytes)
+// fp32 split-K slab store, write-through (sc1): the 4-17 MB of partials a split launch leaves are already on their way
+// to memory when the kernel ends instead of being written back at the boundary (MI355X_MICROARCH.md publish-large /
+// boundary: + B / 6 TB/s behind B dirty bytes).  Same-box A/B on the forward: 2.946 -> 2.941 ms.
 __device__ __forceinline__ void slab_store(float* p, f32x4 v) {
-#ifdef UPK_SC1_SLAB
   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-#else
-  *(f32x4*)p = v;
-#endif
 }
 
 // KS = K-chunks (of 32) staged per barrier.  UNet launches have only 1-4 workgroups per CU,
@@ -430,9 +426,6 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
       bp[i] = a.w + (long)ph * a.ph_wstride + ((long)kc0 * a.npad + n0 + row) * 32 + chd * 8;
     }
     const long wstep = (long)a.npad * 32;
-#ifdef UPK_NT_W
-    const bool w_nt = a.partial != nullptr && a.tiles_m <= 4;
-#endif
 
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
@@ -455,12 +448,8 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
           const int rg = lw + 4 * i;
           const f16* src = (live && b_ok[i]) ? bp[i] : zsrc;
           f16* dst = (rg < BG) ? base + (s * ROWS + BM + rg * 16) * 32 : smem + NBUF * STAGE;
-#ifdef UPK_NT_W
-          // split-K launches (the 8x8 / 4x4 levels): a weight line is read by the one or two workgroups of its K slice,
-          // once — nontemporal: it does not displace the activations in L2 (MI355X_MICROARCH.md nt-weights)
-          if (w_nt) __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)dst, 16, 0, 2);
-          else
-#endif
+          // (nt on the weight stream of the split-K launches — each line read once by one or two workgroups — measured
+          // +70 us on the forward, 2.946 -> 3.015 ms: the slices ARE shared across the XCD's M tiles through L2)
           __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)dst, 16, 0, 0);
           bp[i] += wstep;
         }
