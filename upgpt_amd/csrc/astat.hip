@@ -475,12 +475,9 @@ bool astat_plan(const upk_ctx* ctx, const IgemmArgs& a, int c, int ppw_req, AsPl
 
 int astat_launch(upk_ctx* ctx, IgemmArgs& a, int c, const AsPlan& pl, dim3 grid, hipStream_t stream) {
   const AsCfg& k = kAsCfgs[c];
-  static bool attr_set[kNumAsCfgs] = {};
-  if (!attr_set[c]) {
-    UPK_HIP(ctx, hipFuncSetAttribute((const void*)k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    UPK_HIP(ctx, hipFuncSetAttribute((const void*)k.fn_gen, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set[c] = true;
-  }
+  static unsigned long long attr_set[kNumAsCfgs][2] = {};
+  if (int rc = upk_lds_attr_once(ctx, (const void*)k.fn, &attr_set[c][0])) return rc;
+  if (int rc = upk_lds_attr_once(ctx, (const void*)k.fn_gen, &attr_set[c][1])) return rc;
   const bool geglu = a.flags & UPK_F_GEGLU;
   const bool fast = geglu ? Epi::plain_geglu(a) : (Epi::plain(a) && !a.gn_cp && !a.lnr_out && !a.rowvec);
   a.as_ppw = pl.ppw;

@@ -99,6 +99,19 @@ struct upk_prof_scope {
   }
 };
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute of a kernel: set once per (kernel, device), under
+// a lock (contexts of several GPUs / threads share the library).  `mask`: one static per kernel, bit = device ordinal.
+#include <mutex>
+static inline int upk_lds_attr_once(upk_ctx* ctx, const void* fn, unsigned long long* mask) {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  const unsigned long long bit = 1ull << (ctx->device & 63);
+  if (*mask & bit) return UPK_OK;
+  UPK_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  *mask |= bit;
+  return UPK_OK;
+}
+
 static inline int upk_check_launch(upk_ctx* ctx, const char* what) {
   if (ctx) ++ctx->n_kernels;
   hipError_t e = hipGetLastError();

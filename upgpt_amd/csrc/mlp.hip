@@ -352,12 +352,8 @@ extern "C" int upk_geglu_mlp_f16(upk_ctx* ctx, const upk_mlp_desc* d, upk_stream
 #endif
   const size_t lds = (size_t)(s.nch1 + s.nh) * bm * 64 + (size_t)bm * 8 + (size_t)s.n1 * 8;
   void (*fn)(const MlpArgs) = bm == 32 ? mlp_kernel<2, 7> : mlp_kernel<4, 7>;
-  static bool attr32 = false, attr64 = false;
-  bool& done = bm == 32 ? attr32 : attr64;
-  if (!done) {
-    UPK_HIP(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    done = true;
-  }
+  static unsigned long long attr32 = 0, attr64 = 0;
+  if (int rc = upk_lds_attr_once(ctx, (const void*)fn, bm == 32 ? &attr32 : &attr64)) return rc;
   upk_prof_scope prof(ctx, UPK_CLS_IGEMM, stream);
   hipLaunchKernelGGL(fn, dim3((s.M + bm - 1) / bm), dim3(512), lds, stream, s);
   return upk_check_launch(ctx, "geglu_mlp");

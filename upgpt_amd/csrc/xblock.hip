@@ -672,13 +672,13 @@ namespace {
 struct XbCfg {
   int c, dp, bm;
   void (*fn)(const XbArgs);
-  bool attr_done;
+  unsigned long long attr_done;  // (devices on which the LDS attribute is set)
 };
 XbCfg g_xb[] = {
-    {224, 32, 32, xblock_kernel<2, 7, 32, 8, 7>, false},
-    {224, 32, 16, xblock_kernel<1, 7, 32, 8, 7>, false},
-    {448, 64, 32, xblock_kernel<2, 14, 64, 4, 2>, false},
-    {448, 64, 16, xblock_kernel<1, 14, 64, 4, 7>, false},
+    {224, 32, 32, xblock_kernel<2, 7, 32, 8, 7>, 0},
+    {224, 32, 16, xblock_kernel<1, 7, 32, 8, 7>, 0},
+    {448, 64, 32, xblock_kernel<2, 14, 64, 4, 2>, 0},
+    {448, 64, 16, xblock_kernel<1, 14, 64, 4, 7>, 0},
 };
 XbCfg* xb_find(const upk_xblock_desc* d) {
   const int bm = d->rows_per_wg > 0 ? d->rows_per_wg : 32;
@@ -725,10 +725,7 @@ extern "C" int upk_cross_block_f16(upk_ctx* ctx, const upk_xblock_desc* d, upk_s
 #endif
   const int bm = cfg->bm;
   const size_t lds = (size_t)(hd / 32 + d->c / 32) * bm * 64 + (size_t)bm * 8 + (size_t)s.vec_pieces * 1024;
-  if (!cfg->attr_done) {
-    UPK_HIP(ctx, hipFuncSetAttribute((const void*)cfg->fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    cfg->attr_done = true;
-  }
+  if (int rc = upk_lds_attr_once(ctx, (const void*)cfg->fn, &cfg->attr_done)) return rc;
   upk_prof_scope prof(ctx, UPK_CLS_ATTN, stream);
   hipLaunchKernelGGL(cfg->fn, dim3(d->m / bm), dim3(512), lds, stream, s);
   return upk_check_launch(ctx, "cross_block");
@@ -778,6 +775,8 @@ extern "C" int upk_head_block_f16(upk_ctx* ctx, const upk_hblock_desc* d, upk_st
                                       : (gnf ? hblock_kernel<1, 7, 32, true> : hblock_kernel<1, 7, 32, false>);
   const size_t lds = (size_t)2 * (d->c / 32) * bm * 64 + (size_t)bm * 8 + (size_t)s.vec_pieces * 1024 +
                      (gnf ? (size_t)2 * d->c * 4 + 2 * UPK_GN_GROUPS_MAX * 8 + 2 * UPK_GN_GROUPS_MAX * 4 : 0);
+  static unsigned long long hb_attr[4] = {};
+  if (int rc = upk_lds_attr_once(ctx, (const void*)fn, &hb_attr[(bm == 32 ? 0 : 2) + (gnf ? 1 : 0)])) return rc;
   upk_prof_scope prof(ctx, UPK_CLS_IGEMM, stream);
   hipLaunchKernelGGL(fn, dim3(d->m / bm), dim3(512), lds, stream, s);
   return upk_check_launch(ctx, "head_block");

@@ -787,6 +787,13 @@ class Emitter:
             a = (x.t.data_ptr(), x.C, x.ld, None, 0, 0, x.B, hw, 32, gamma.data_ptr(), beta.data_ptr(), float(eps), 0,
                  xn.t.data_ptr(), xn.ld)
             src, sws = armed[0]
+            mine = None
+            if GN_REDUCE_APPLY and not isinstance(src, Emitter.GnProvider) and not src.gno_y:
+                # a producer that splits K normalises in its reduce pass (include/upk.h gno_*), as Emitter.groupnorm arms
+                # it: the head then reads xn and runs without the in-kernel GroupNorm
+                mine = src
+                mine.gno_gamma, mine.gno_beta, mine.gno_eps = gamma.data_ptr(), beta.data_ptr(), float(eps)
+                mine.gno_silu, mine.gno_y, mine.gno_ld, mine.gno_skip_y = 0, xn.t.data_ptr(), xn.ld, 0
 
             def run(s):
                 if isinstance(src, Emitter.GnProvider):
@@ -794,7 +801,11 @@ class Emitter:
                 else:
                     m_, n_ = C.c_int(0), C.c_int(0)
                     chk(fused_fn(h, C.byref(src), C.byref(m_), C.byref(n_)))
-                    mode, nb, ld = (m_.value if m_.value != 3 else 0), n_.value, src.n_pad
+                    mode, nb, ld = (m_.value if m_.value != 3 or src is mine else 0), n_.value, src.n_pad
+                if mode == 3:  # (xn was written by the producer's reduce pass)
+                    d.x, d.ldx, d.gn_part = xn.t.data_ptr(), xn.ld, None
+                    chk(fn(h, C.byref(d), s))
+                    return
                 if mode == 2 and nb <= 32:
                     d.x, d.ldx = x.t.data_ptr(), x.ld
                     d.gn_part, d.gn_gamma, d.gn_beta = sws.data_ptr(), gamma.data_ptr(), beta.data_ptr()
