@@ -105,7 +105,7 @@ def kernel_class_profile(model, wl, reps=20):
     in eager mode over-reads 10-us kernels by 20-30 %: eager launching is host-bound.)"""
     import ctypes as C
     from upgpt_amd._lib import get_context
-    ctx = get_context(0)
+    ctx = get_context(torch.cuda.current_device())  # (the rank's own GPU, set by main())
     unet = model.model.diffusion_model
     B, (H, W) = wl.B, wl.hw
     with model.ema_scope():
