@@ -615,15 +615,4 @@ int bt_launch(upk_ctx* ctx, const IgemmArgs& a, int c, dim3 grid, hipStream_t st
 
 
 
-// halo.hip: the halo-patch 3x3 family (configurations behind the big-tile ones): input patch resident in LDS, weights
-// streamed into registers by eight waves (4 K slices x 2 N halves); second tuning slot = split-K over channel ranges
-struct HcPlan {
-  int bm, bn, splitk, lds_bytes, cp_off, tab_off;
-  int pw, part_pix, npix, ngrp, cr, nslot, cpt, mps, aps, sh_hw, sh_w, pp_magic, pw_magic;
-};
-int hc_num_configs();
-const char* hc_config_name(int c);
-bool hc_plan(const upk_ctx* ctx, const IgemmArgs& a, int c, int splitk, HcPlan* pl);
-int hc_launch(upk_ctx* ctx, const IgemmArgs& a, int c, const HcPlan& pl, dim3 grid, hipStream_t stream);
-
 }  // namespace upkd
