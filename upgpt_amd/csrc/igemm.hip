@@ -505,6 +505,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
 #else
     if constexpr (!KSPLIT) {
       if constexpr (SHARE) {
+        if ABL_ON(ABL_NOEPI) return;
         if (Epi::plain(a) && !a.partial && !a.lnr_out) {  // (workgroup-uniform: the MFMA waves take the same branch)
           const int pwm = lw / WN, pwn = lw - pwm * WN;   // the MFMA wave beside this one
           const int lg = lane >> 4, lc = lane & 15;
