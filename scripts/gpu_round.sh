@@ -11,3 +11,4 @@ timeout 900 python bench.py --steps 5 --warmup 2 > gpurun_out/bench_r04.json 2> 
 bash scripts/gpu_prof.sh > gpurun_out/prof.log 2>&1
 bash scripts/gpu_optrace.sh 32 32 > /dev/null 2>&1; tail -8 gpurun_out/ot_table_32x32.txt
 bash scripts/gpu_optrace_vae.sh 32 32 > /dev/null 2>&1; tail -8 gpurun_out/ot_vae_32x32.txt
+timeout 1500 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --cfg 3 --encoders --upscale > gpurun_out/bench_secondary.json 2> gpurun_out/bench_secondary.err; tail -c 1200 gpurun_out/bench_secondary.json
