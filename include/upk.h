@@ -55,7 +55,8 @@ int upk_version(void);
 int upk_create(upk_ctx** out, int device);
 int upk_destroy(upk_ctx* ctx);
 const char* upk_last_error(upk_ctx* ctx);
-/* Caller-owned scratch for split-K partial sums (fp32).  May be NULL/0. */
+/* Caller-owned scratch for split-K partial sums (fp16 slabs [z][m][n_pad], accumulated in fp32 inside each slice and
+ * summed in fp32 by the reduce pass; fixed slice order, so results are deterministic).  May be NULL/0. */
 int upk_set_workspace(upk_ctx* ctx, void* dptr, size_t bytes);
 /* Number of compute units of the bound device (256 on MI355X). */
 int upk_num_cus(upk_ctx* ctx);

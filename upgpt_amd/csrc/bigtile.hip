@@ -340,7 +340,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2, 
   const int nw = n0 + wn * (NI * 16);
   if (a.lnr_in) Epi::lnr_fix<MI, NI>(a, mw, nw, lc, lg, acc);
   if (a.partial) {
-    float* slab = a.partial + ((long)zs * (a.ph_on ? 4 : 1) + ph) * a.M * a.npad;
+    slab_t* slab = (slab_t*)a.partial + ((long)zs * (a.ph_on ? 4 : 1) + ph) * a.M * a.npad;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = mw + i * 16 + lc;
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2, 
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const int n = nw + j * 16 + lg * 4;
-        if (n < a.npad) *(f32x4*)(slab + roff + n) = acc[i][j];
+        if (n < a.npad) slab_store(slab + roff + n, acc[i][j]);
       }
     }
     return;

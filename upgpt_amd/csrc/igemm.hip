@@ -24,13 +24,6 @@ namespace {
 using namespace upkd;
 
 
-// fp32 split-K slab store, write-through (sc1): the 4-17 MB of partials a split launch leaves are already on their way
-// to memory when the kernel ends instead of being written back at the boundary (MI355X_MICROARCH.md publish-large /
-// boundary: + B / 6 TB/s behind B dirty bytes).  Same-box A/B on the forward: 2.946 -> 2.941 ms.
-__device__ __forceinline__ void slab_store(float* p, f32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-}
-
 // KS = K-chunks (of 32) staged per barrier.  UNet launches have only 1-4 workgroups per CU,
 // so latency must be hidden INSIDE a workgroup: KS chunks of global loads are in flight
 // at once and KS*MI*NI MFMAs run between two barriers.
@@ -242,7 +235,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
     return;
   }
   if (a.partial) {
-    float* slab = a.partial + ((long)zs * (a.ph_on ? 4 : 1) + ph) * a.M * a.npad;  // uniform base
+    slab_t* slab = (slab_t*)a.partial + ((long)zs * (a.ph_on ? 4 : 1) + ph) * a.M * a.npad;  // uniform base
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = mw + i * 16 + lc;
@@ -251,7 +244,7 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const IgemmArgs a) {
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const int n = nw + j * 16 + lg * 4;
-        if (n < a.npad) slab_store(slab + roff + n, acc[i][j]);
+        if (n < a.npad && !ABL_ON(ABL_NOSLAB)) slab_store(slab + roff + n, acc[i][j]);
       }
     }
     return;
@@ -517,7 +510,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
 #pragma unroll
             for (int j = 0; j < NJ1; ++j) acc2[i][j] = *(const f32x4*)(hand + ((i * NJ1 + j) * 64 + lane) * 4);
           const int mw = m0 + pwm * (MI * 16), nw = n0 + pwn * (NI * 16) + NJ0 * 16;
-          if (a.gn_cp) Epi::tile_plain_cp<MI, NJ1, WM, WN, NI>(a, m0, mw, nw, lc, lg, acc2, pwm, pwn, (float*)smem, a.M, NJ0);
+          if (a.gn_cp && !ABL_ON(ABL_NOGNP)) Epi::tile_plain_cp<MI, NJ1, WM, WN, NI>(a, m0, mw, nw, lc, lg, acc2, pwm, pwn, (float*)smem, a.M, NJ0);
           else Epi::tile_plain<MI, NJ1>(a, mw, nw, lc, lg, acc2, a.M);
         }
       }
@@ -620,13 +613,13 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
       for (int w = 1; w < 4; ++w) v += *(const f32x4*)(red + ((w * NF + f) * 64 + lane) * 4);
       return v;
     };
-    float* slab = a.partial ? a.partial + ((long)zs * (a.ph_on ? 4 : 1) + ph) * a.M * a.npad : nullptr;
+    slab_t* slab = a.partial ? (slab_t*)a.partial + ((long)zs * (a.ph_on ? 4 : 1) + ph) * a.M * a.npad : nullptr;
     if (slab) {
       for (int f = wave; f < NF; f += EW) {  // fragment f = (i, j) is finished by wave f % 8
         const int i = f / NI, j = f - i * NI;
         const int m = m0 + i * 16 + lc;
         const int n = n0 + j * 16 + lg * 4;
-        if (n < a.npad && m < a.M) slab_store(slab + (unsigned)m * (unsigned)a.npad + n, frag_sum(f));
+        if (n < a.npad && m < a.M && !ABL_ON(ABL_NOSLAB)) slab_store(slab + (unsigned)m * (unsigned)a.npad + n, frag_sum(f));
       }
       return;
     }
@@ -796,7 +789,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
     return;
   }
   if (a.partial) {
-    float* slab = a.partial + ((long)zs * (a.ph_on ? 4 : 1) + ph) * a.M * a.npad;
+    slab_t* slab = (slab_t*)a.partial + ((long)zs * (a.ph_on ? 4 : 1) + ph) * a.M * a.npad;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int m = mw + i * 16 + lc;
@@ -805,7 +798,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const int n = nw + j * 16 + lg * 4;
-        if (n < a.npad) slab_store(slab + roff + n, acc[i][j]);
+        if (n < a.npad && !ABL_ON(ABL_NOSLAB)) slab_store(slab + roff + n, acc[i][j]);
       }
     }
     return;
@@ -823,7 +816,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (a.gn_cp) Epi::tile_plain_cp<MI, NJ0, WM, WN, NI>(a, m0, mw, nw, lc, lg, acc1, wm, wn, (float*)smem, a.M, 0);
+      if (a.gn_cp && !ABL_ON(ABL_NOGNP)) Epi::tile_plain_cp<MI, NJ0, WM, WN, NI>(a, m0, mw, nw, lc, lg, acc1, wm, wn, (float*)smem, a.M, 0);
       else Epi::tile_plain<MI, NJ0>(a, mw, nw, lc, lg, acc1, a.M);
 #ifdef UPK_TIMELINE
       if (wave == 0) {
@@ -853,21 +846,21 @@ __global__ __launch_bounds__(256) void igemm_reduce_kernel(const IgemmArgs a, in
   const int m = (int)(idx / nq);
   const int n = (int)(idx - (long)m * nq) * 4;
   const long slab = (long)a.M * a.npad * (a.ph_on ? 4 : 1);  // (phase launches: slabs [z][phase], grid.y = phase)
-  const float* p = a.partial + ((long)ph_id(a) * a.M + m) * a.npad + n;
+  const slab_t* p = (const slab_t*)a.partial + ((long)ph_id(a) * a.M + m) * a.npad + n;
   f32x4 v = {0, 0, 0, 0}, g = {0, 0, 0, 0};
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   if (a.flags & UPK_F_GEGLU) {
     if (n & 32) return;  // gate columns are consumed by their value partner
     for (int z = 0; z < splitk; ++z) {
-      v += *(const f32x4*)(p + z * slab);
-      g += *(const f32x4*)(p + z * slab + 32);
+      v += slab_load4(p + z * slab);
+      g += slab_load4(p + z * slab + 32);
     }
   } else {
     // four slabs in flight (a one-load-per-iteration loop with a runtime trip count runs at the latency of a load)
     for (int z0 = 0; z0 < splitk; z0 += 4) {
       f32x4 t[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) t[u] = z0 + u < splitk ? *(const f32x4*)(p + (long)(z0 + u) * slab) : z4;
+      for (int u = 0; u < 4; ++u) t[u] = z0 + u < splitk ? slab_load4(p + (long)(z0 + u) * slab) : z4;
 #pragma unroll
       for (int u = 0; u < 4; ++u) v += t[u];  // (slab order, as before)
     }
@@ -904,6 +897,13 @@ struct VecIO {
     } else {
       o[0] = on ? *p : 0.f;
     }
+  }
+  static __device__ __forceinline__ void lds(const slab_t* p, bool on, float (&o)[V]) {  // (a split-K slab element)
+#ifdef UPK_SLAB_F32
+    ldf(p, on, o);
+#else
+    ldh(p, on, o);
+#endif
   }
   static __device__ __forceinline__ void ldh(const f16* p, bool on, float (&o)[V]) {
     if constexpr (V == 4) {
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(256) void igemm_reduce_gnapply_kernel(const IgemmAr
     const int m = b * g.hw + p;
     mrow[k] = on ? m : -1;
     ncol[k] = n;
-    const float* pp = a.partial + (long)m * a.npad + n;
+    const slab_t* pp = (const slab_t*)a.partial + (long)m * a.npad + n;
     float acc[V], cb[V], cr[V], cs[V];
     IO::ldf(g.gamma + n, on, ga[k]);  // (not needed before the group reduction: in flight with the slabs)
     IO::ldf(g.beta + n, on, be[k]);
@@ -964,7 +964,7 @@ __global__ __launch_bounds__(256) void igemm_reduce_gnapply_kernel(const IgemmAr
 #pragma unroll
       for (int zz = 0; zz < 4; ++zz) {
         const bool zon = on && z0 + zz < splitk;
-        IO::ldf(pp + (long)(zon ? z0 + zz : 0) * slab, zon, t[zz]);
+        IO::lds(pp + (long)(zon ? z0 + zz : 0) * slab, zon, t[zz]);
       }
 #pragma unroll
       for (int zz = 0; zz < 4; ++zz)
@@ -1058,12 +1058,12 @@ __global__ __launch_bounds__(256) void igemm_reduce_gn_kernel(const IgemmArgs a,
     const long slab = (long)a.M * a.npad;
     for (int p = p0 + r; p < p1; p += rpi) {
       const long m = (long)b * gf.hw + p;
-      const float* pp = a.partial + m * a.npad + n;
+      const slab_t* pp = (const slab_t*)a.partial + m * a.npad + n;
       f32x4 v0 = c0, v1 = c1;
 #pragma unroll 4
       for (int z = 0; z < splitk; ++z) {
-        v0 += *(const f32x4*)(pp + z * slab);
-        v1 += *(const f32x4*)(pp + z * slab + 4);
+        v0 += slab_load4(pp + z * slab);
+        v1 += slab_load4(pp + z * slab + 4);
       }
       if (a.res) {
         const f16x8 rr = *(const f16x8*)(a.res + m * a.ldr + n);
@@ -1352,7 +1352,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     a.nchunks += (a.c3 + a.c4) / 32;
   }
   a.flags = flags;
-  if (const char* ab = getenv("UPK_ABLATE")) a.flags |= (int)strtol(ab, nullptr, 0) & 0x3F0000;
+  if (const char* ab = getenv("UPK_ABLATE")) a.flags |= (int)strtol(ab, nullptr, 0) & 0x3FF0000;
   a.dbg = (unsigned long long*)((char*)ctx->ws + ctx->ws_bytes - 4096);
 
   // ---- choose config + split-K ----
@@ -1360,7 +1360,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   double best_t = 1e30;
   const int sk_cands[] = {1, 2, 3, 4, 6, 8, 9, 12, 16, 18};
   const int nph = a.ph_on ? 4 : 1;
-  const size_t slab = (size_t)a.M * a.npad * sizeof(float) * nph;
+  const size_t slab = (size_t)a.M * a.npad * sizeof(slab_t) * nph;
   const int want_cfg = ctx->cfg_override >= 0 ? ctx->cfg_override : (d->tune_cfg > 0 ? d->tune_cfg - 1 : -1);
   const int want_sk = ctx->splitk_override > 0 ? ctx->splitk_override : (d->tune_splitk > 0 ? d->tune_splitk : 0);
   if (want_cfg >= upk_conv_num_configs())

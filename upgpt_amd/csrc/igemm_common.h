@@ -14,6 +14,10 @@ enum {
   ABL_NOMFMA = 0x80000,
   ABL_EMPTY = 0x100000,  // WS kernel returns at entry (pure launch cost of its geometry)
   ABL_TIMELINE = 0x200000,  // WS kernel: blocks 0 and gridDim.x-1 write s_memtime stamps to the workspace
+  ABL_NOSTORE = 0x400000,   // plain epilogue: everything but the global stores of the output
+  ABL_NOGNP = 0x800000,     // plain epilogue: no GroupNorm channel partials (column sums, LDS exchange, their stores)
+  ABL_NOEPILD = 0x1000000,  // plain epilogue: operands (bias, row vector, residual) read as zeros, no loads
+  ABL_NOSLAB = 0x2000000,   // split-K launches: the fp32 partial slabs are not written
 };
 // The ablation / timeline hooks are compiled in only for dev builds (UPK_CXXFLAGS=-DUPK_DEV, scripts/ablate.sh,
 // scripts/timeline*.py): even as never-taken runtime tests they cost scalar registers and instructions in the loops.
@@ -87,6 +91,33 @@ struct IgemmArgs {
   // [tn * as_ppw, min(as_npass, (tn + 1) * as_ppw)) of 8 waves x NI x 16 output columns; tiles_n = N super tiles
   int as_ppw, as_npass;
 };
+
+// Split-K partial slabs ([split][M][n_pad] in the caller's workspace, IgemmArgs::partial).  fp16: the partial sums are
+// rounded once on their way out and added in fp32 by the reduce pass, in slab order (deterministic as before) — half
+// the bytes of the fp32 slabs, which cost 80 us of the forward on their way out alone (phase ablation,
+// profiles/r04_forward_phase_ablation_igemm_ws.txt).  Error: one extra fp16 rounding per partial, ~|y| 2^-11 in
+// total for z partials of magnitude |y| / sqrt z — the size of the output's own rounding.  -DUPK_SLAB_F32: fp32 slabs.
+#ifdef UPK_SLAB_F32
+typedef float slab_t;
+typedef f32x4 slab4;
+#else
+typedef f16 slab_t;
+typedef f16x4 slab4;
+#endif
+// write-through (sc1): the partials are on their way to memory when the kernel ends instead of being written back
+// at the boundary (MI355X_MICROARCH.md publish-large / boundary); same-box A/B on the forward: 2.946 -> 2.941 ms
+__device__ __forceinline__ void slab_store(slab_t* p, f32x4 v) {
+#ifdef UPK_SLAB_F32
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#else
+  const f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(h) : "memory");
+#endif
+}
+__device__ __forceinline__ f32x4 slab_load4(const slab_t* p) {
+  const slab4 v = *(const slab4*)p;
+  return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
 
 // (tm, tn, split index) of this workgroup; false: nothing to do (XCD-aware grids are padded)
 __device__ __forceinline__ bool tile_map(const IgemmArgs& a, int& tm, int& tn, int& zs) {
@@ -340,6 +371,7 @@ struct Epi {
       hw = a.Ho * a.Wo;
     }
     __device__ __forceinline__ f32x4 bias4(const IgemmArgs& a, int n) const {
+      if ABL_ON(ABL_NOEPILD) return (f32x4){0.f, 0.f, 0.f, 0.f};
       return *(const f32x4*)(bias + ((n < a.npad ? (unsigned)n : 0u) & has_b));
     }
     // row part: offsets of row m (clamped to a valid row; the store is predicated on m < M)
@@ -357,16 +389,18 @@ struct Epi {
       return r;
     }
     __device__ __forceinline__ f32x4 rv4(const IgemmArgs& a, const Row& r, int n) const {
+      if ABL_ON(ABL_NOEPILD) return (f32x4){0.f, 0.f, 0.f, 0.f};
       return *(const f32x4*)(rvp + ((r.rv_off + (n < a.n_out ? (unsigned)n : 0u)) & has_rv));
     }
     __device__ __forceinline__ f16x4 res4(const IgemmArgs& a, const Row& r, int n) const {
+      if ABL_ON(ABL_NOEPILD) return (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
       return *(const f16x4*)(resp + r.res_off + ((n < a.n_out ? (unsigned)n : 0u) & has_res));
     }
     static __device__ __forceinline__ f16x4 put(const IgemmArgs& a, const Row& r, int n, f32x4 v, const f16x4 rr) {
       f16x4 o;
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] = (f16)(v[k] + (float)rr[k]);
-      if (r.ok && n < a.n_out) *(f16x4*)((f16*)a.y + r.y_off + n) = o;
+      if (r.ok && n < a.n_out && !ABL_ON(ABL_NOSTORE)) *(f16x4*)((f16*)a.y + r.y_off + n) = o;
       return o;
     }
   };
@@ -561,7 +595,7 @@ struct Epi {
   static __device__ __forceinline__ void tile(const IgemmArgs& a, int m0, int mw, int nw, int lc, int lg,
                                               const f32x4 (&acc)[MI][NI], int wm, int wn, float* red, int mlim) {
     if (plain(a)) {
-      if (a.gn_cp) tile_plain_cp<MI, NI, WM, WN>(a, m0, mw, nw, lc, lg, acc, wm, wn, red, mlim);
+      if (a.gn_cp && !ABL_ON(ABL_NOGNP)) tile_plain_cp<MI, NI, WM, WN>(a, m0, mw, nw, lc, lg, acc, wm, wn, red, mlim);
       else if (a.lnr_out) tile_plain_lnr<MI, NI>(a, mw, nw, lc, lg, acc, mlim);
       else tile_plain<MI, NI>(a, mw, nw, lc, lg, acc, mlim);
       return;
