@@ -197,22 +197,6 @@ typedef struct upk_conv_desc {
    * launches with many M tiles per sample — the VAE decoder's 64x64 ... 256x256 feature maps — leave their partials
    * too; a consumer then folds them with upk_groupnorm_finalize_f32 before upk_groupnorm_apply_nhwc_f16 (mode 1). */
   int32_t gn_stats_cap;
-  /* GroupNorm (+ SiLU) of the INPUT applied by the conv itself (ResBlock in_layers / out_layers: GroupNorm32 -> SiLU ->
-   * conv3x3, openaimodel.py:203-206, 227-233): x1 | x2 are the UN-normalised tensors and gni_stats1 / gni_stats2 the
-   * per-(row block, channel) partial sums their producers left (gn_stats_ws mode 2 layout, [batch][nblk][2][ld],
-   * nblk <= 32).  Only the halo-patch 3x3 family can do this — it stages each input pixel once, through registers, on
-   * its way to LDS (scale / shift / SiLU once per pixel instead of once per tap); every workgroup folds the partials
-   * of its sample into the per-channel scale / shift table with the arithmetic of upk_groupnorm_apply_nhwc_f16, so the
-   * result is bit-identical to that launch followed by the same conv.  The appended 1x1 sources x3 | x4 are not
-   * normalised.  upk_conv_gn_input() says whether the launch, as it would be dispatched now (tuned / overridden
-   * configuration), takes these fields; a launch that cannot fails with UPK_ESHAPE.  gni_stats1 == NULL: off. */
-  const float* gni_stats1;
-  const float* gni_stats2;
-  int32_t gni_nblk1, gni_ld1, gni_nblk2, gni_ld2;
-  const float* gni_gamma; /* [c1 + c2] */
-  const float* gni_beta;
-  float gni_eps;
-  int32_t gni_groups, gni_silu;
 } upk_conv_desc;
 
 /* Replaces F.conv2d (3x3 s1/s2 p1, 1x1) / F.linear call sites:
@@ -227,10 +211,6 @@ int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream)
  * {0, 1, 2, 3}, *nblk = row blocks per sample for mode 2; 3 = the reduce pass applies the GroupNorm itself (gno_*) and
  * leaves no statistics.  Nothing is enqueued. */
 int upk_conv_gn_fused(upk_ctx* ctx, const upk_conv_desc* d, int* mode, int* nblk);
-/* *ok = 1 when upk_conv2d_nhwc_f16(d) will apply the input GroupNorm described by d->gni_* itself (halo-patch
- * configuration, whole K range of a workgroup resident in LDS, one sample per tile), else 0: the caller then runs
- * upk_groupnorm_apply_nhwc_f16 first and clears gni_stats1.  Nothing is enqueued. */
-int upk_conv_gn_input(upk_ctx* ctx, const upk_conv_desc* d, int* ok);
 /* Folds per-(row block, channel) partials ([batch][nblk][2][ld], any nblk) into the per-(chunk, group) layout of
  * upk_groupnorm_nhwc_f16's workspace (everything in chunk 0, zeros elsewhere), so that
  * upk_groupnorm_apply_nhwc_f16(..., stats = ws, stats_mode = 1, ...) can follow: GroupNorm of a tensor whose producer

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("UPK_LIB") or os.path.join(_HERE, "libupk.so")  # (UPK
 SYMBOLS = [
     "upk_version", "upk_create", "upk_destroy", "upk_last_error", "upk_set_workspace", "upk_num_cus",
     "upk_pack_weight_f16", "upk_packed_weight_bytes", "upk_conv2d_nhwc_f16", "upk_gemm_f16",
-    "upk_conv_autotune", "upk_conv_override", "upk_conv_num_configs", "upk_conv_config_name", "upk_conv_gn_fused", "upk_conv_gn_input",
+    "upk_conv_autotune", "upk_conv_override", "upk_conv_num_configs", "upk_conv_config_name", "upk_conv_gn_fused",
     "upk_conv_ln_rows",
     "upk_geglu_mlp_f16", "upk_geglu_mlp_supported", "upk_cross_block_f16", "upk_cross_block_supported", "upk_head_block_f16", "upk_head_block_supported",
     "upk_attention_f16", "upk_groupnorm_nhwc_f16", "upk_groupnorm_stats_nhwc_f16", "upk_groupnorm_chunks", "upk_groupnorm_apply_nhwc_f16", "upk_groupnorm_finalize_f32", "upk_groupnorm_ws_bytes",
@@ -66,10 +66,6 @@ class ConvDesc(C.Structure):
         ("gno_silu", C.c_int32), ("gno_ld", C.c_int32), ("gno_skip_y", C.c_int32),
         ("ln_rows_out", C.c_void_p), ("ln_rows_in", C.c_void_p), ("ln_rows_slots", C.c_int32),
         ("w_phase", C.c_void_p), ("gn_stats_cap", C.c_int32),
-        ("gni_stats1", C.c_void_p), ("gni_stats2", C.c_void_p),
-        ("gni_nblk1", C.c_int32), ("gni_ld1", C.c_int32), ("gni_nblk2", C.c_int32), ("gni_ld2", C.c_int32),
-        ("gni_gamma", C.c_void_p), ("gni_beta", C.c_void_p), ("gni_eps", C.c_float),
-        ("gni_groups", C.c_int32), ("gni_silu", C.c_int32),
     ]
 
 
@@ -166,7 +162,6 @@ def load_library(path=None):
             "upk_groupnorm_apply_nhwc_f16": (C.c_int, [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp,
                                                        f32, i32, vp, i32, vp, i32, i32, i32, vp, i32, i32, vp]),
             "upk_conv_gn_fused": (C.c_int, [vp, C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
-            "upk_conv_gn_input": (C.c_int, [vp, C.POINTER(ConvDesc), C.POINTER(C.c_int)]),
             "upk_groupnorm_finalize_f32": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
             "upk_groupnorm_ws_bytes": (C.c_size_t, [i32, i32]),
             "upk_layernorm_f16": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, f32, vp, i32, vp]),
@@ -288,12 +283,6 @@ class Context:
         f, n = C.c_int(0), C.c_int(0)
         self._chk(self.lib.upk_conv_gn_fused(self.h, C.byref(desc), C.byref(f), C.byref(n)))
         return f.value, n.value
-
-    def conv_gn_input(self, desc):
-        """Whether the launch of `desc` applies its input GroupNorm (gni_*) itself (include/upk.h)."""
-        ok = C.c_int(0)
-        self._chk(self.lib.upk_conv_gn_input(self.h, C.byref(desc), C.byref(ok)))
-        return bool(ok.value)
 
     def gn_stats_floats(self, batch, n_pad, cap=32):
         """Size (floats) of a upk_conv_desc.gn_stats_ws buffer (cap = upk_conv_desc.gn_stats_cap row blocks)."""

@@ -1210,11 +1210,8 @@ double estimate(const CfgInfo& c, int M, int npad, int nchunks, int splitk, int 
 // configurations kNumCfgs .. kNumCfgs + astat_num_configs() - 1 are the A-stationary family (astat.hip); for those the
 // "split-K" slot of the tuning pair means output-column passes per workgroup (0 = fill the chip once)
 // ... and behind those the big-tile family (bigtile.hip); its second slot is a split-K factor like the first families'
-// ... and behind those the halo-patch 3x3 family (halo.hip); second slot = split-K factor over channel ranges
-extern "C" int upk_conv_num_configs(void) { return kNumCfgs + astat_num_configs() + bt_num_configs() + hc_num_configs(); }
+extern "C" int upk_conv_num_configs(void) { return kNumCfgs + astat_num_configs() + bt_num_configs(); }
 extern "C" const char* upk_conv_config_name(int cfg) {
-  if (cfg >= kNumCfgs + astat_num_configs() + bt_num_configs())
-    return hc_config_name(cfg - kNumCfgs - astat_num_configs() - bt_num_configs());
   if (cfg >= kNumCfgs + astat_num_configs()) return bt_config_name(cfg - kNumCfgs - astat_num_configs());
   if (cfg >= kNumCfgs) return astat_config_name(cfg - kNumCfgs);
   return (cfg >= 0 && cfg < kNumCfgs) ? kCfgs[cfg].name : "?";
@@ -1230,9 +1227,8 @@ extern "C" int upk_conv_override(upk_ctx* ctx, int cfg, int splitk) {
 // launch == false: stops after the (config, split-K) decision and reports whether the reduce pass will
 // produce GroupNorm partials (upk_conv_gn_fused)
 static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, bool launch, int* gn_fused,
-                     int* gn_nblk = nullptr, int* lnr_slots = nullptr, int* gni_ok = nullptr) {
+                     int* gn_nblk = nullptr, int* lnr_slots = nullptr) {
   if (lnr_slots) *lnr_slots = 0;
-  if (gni_ok) *gni_ok = 0;
   if (!ctx || !d) return UPK_EINVAL;
   hipStream_t stream = (hipStream_t)stream_;
   if (!d->x1 || !d->w_packed || !d->y) return upk_fail(ctx, UPK_EINVAL, "conv: null x1/w/y");
@@ -1355,12 +1351,6 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     a.ld4 = d->ld4;
     a.nchunks += (a.c3 + a.c4) / 32;
   }
-  if (d->gni_stats1) {  // GroupNorm of the input inside the launch (halo-patch family only: checked with its plan)
-    a.gni_st1 = d->gni_stats1, a.gni_st2 = d->c2 > 0 ? d->gni_stats2 : nullptr;
-    a.gni_nblk1 = d->gni_nblk1, a.gni_ld1 = d->gni_ld1, a.gni_nblk2 = d->gni_nblk2, a.gni_ld2 = d->gni_ld2;
-    a.gni_gamma = d->gni_gamma, a.gni_beta = d->gni_beta, a.gni_eps = d->gni_eps;
-    a.gni_groups = d->gni_groups, a.gni_silu = d->gni_silu;
-  }
   a.flags = flags;
   if (const char* ab = getenv("UPK_ABLATE")) a.flags |= (int)strtol(ab, nullptr, 0) & 0x3FF0000;
   a.dbg = (unsigned long long*)((char*)ctx->ws + ctx->ws_bytes - 4096);
@@ -1379,25 +1369,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   AsPlan aspl;
   const int bt0 = kNumCfgs + astat_num_configs();
   const bool bt_able = !a.x3 && !(a.ln_u && !a.lnr_in);  // (no appended segment, no fragment-side LayerNorm fold)
-  const int hc0 = bt0 + bt_num_configs();
-  const bool is_hc = want_cfg >= hc0;
-  HcPlan hpl;
-  if (a.gni_st1 && !is_hc) {
-    if (!launch) return UPK_OK;  // (upk_conv_gn_input: no)
-    return upk_fail(ctx, UPK_ESHAPE, "conv: an input GroupNorm (gni_*) needs a halo-patch configuration; ask upk_conv_gn_input first");
-  }
-  if (is_hc) {
-    const int sk = want_sk > 0 ? want_sk : 1;
-    if (!hc_plan(ctx, a, want_cfg - hc0, sk, &hpl) || (sk > 1 && slab * sk > ctx->ws_bytes)) {
-      if (a.gni_st1 && !launch) return UPK_OK;  // (upk_conv_gn_input: no — the caller normalises first and asks again without gni_*)
-      return upk_fail(ctx, UPK_ESHAPE, "conv: halo-patch configuration %s (split-K %d%s) does not fit this launch",
-                      hc_config_name(want_cfg - hc0), sk, a.gni_st1 ? ", input GroupNorm" : "");
-    }
-    if (gni_ok) *gni_ok = hpl.gni;
-    best = want_cfg;
-    best_sk = sk;
-  }
-  bool is_bt = want_cfg >= bt0 && !is_hc;
+  bool is_bt = want_cfg >= bt0;
   int bt_bm = 0, bt_bn = 0, bt_occ = 1, bt_mi = 0, bt_ni = 0, bt_wn = 1;
   if (is_bt) {
     bt_tile(want_cfg - bt0, &bt_bm, &bt_bn, &bt_occ, &bt_mi, &bt_ni, &bt_wn);
@@ -1409,7 +1381,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     best = want_cfg;
     best_sk = sk;
   }
-  const bool is_as = want_cfg >= kNumCfgs && !is_bt && !is_hc;
+  const bool is_as = want_cfg >= kNumCfgs && !is_bt;
   if (is_as) {
     if (!astat_plan(ctx, a, want_cfg - kNumCfgs, want_sk, &aspl) || (want_sk > 1 && want_sk > aspl.npass))
       return upk_fail(ctx, UPK_ESHAPE, "conv: A-stationary configuration %s (passes per workgroup %d) does not fit this launch",
@@ -1417,7 +1389,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     best = want_cfg;
     best_sk = 1;
   }
-  for (int c = 0; c < kNumCfgs && !is_as && !is_bt && !is_hc; ++c) {
+  for (int c = 0; c < kNumCfgs && !is_as && !is_bt; ++c) {
     if (want_cfg >= 0 && c != want_cfg) continue;
     // folded LayerNorm: row statistics come from the M x N-split wave-specialised kernels, whole K in one block
     if (a.ln_u && !a.lnr_in && !kCfgs[c].fn_ln) continue;
@@ -1460,13 +1432,13 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
                       slab * want_sk, ctx->ws_bytes);
     return upk_fail(ctx, UPK_ESHAPE, "conv: no kernel configuration fits (geglu=%d)", (int)geglu);
   }
-  const CfgInfo& c = kCfgs[(is_as || is_bt || is_hc) ? 0 : best];  // (not used by the other families beyond this block)
-  const int BM = is_hc ? hpl.bm : (is_bt ? bt_bm : (is_as ? aspl.bm : c.mi * 16 * c.wm));
-  const int BN = is_hc ? hpl.bn : (is_bt ? bt_bn : (is_as ? aspl.pw * aspl.ppw : c.ni * 16 * c.wn));
+  const CfgInfo& c = kCfgs[(is_as || is_bt) ? 0 : best];  // (not used by the A-stationary / big-tile families beyond this block)
+  const int BM = is_bt ? bt_bm : (is_as ? aspl.bm : c.mi * 16 * c.wm);
+  const int BN = is_bt ? bt_bn : (is_as ? aspl.pw * aspl.ppw : c.ni * 16 * c.wn);
   a.tiles_m = cdiv(a.M, BM);
   a.tiles_n = is_as ? aspl.tiles_n : cdiv(a.npad, BN);
   a.chunks_per_split = cdiv(a.nchunks, best_sk);
-  const int zdim = is_hc ? hpl.splitk : cdiv(a.nchunks, a.chunks_per_split);  // (halo-patch: channel ranges, all non-empty)
+  const int zdim = cdiv(a.nchunks, a.chunks_per_split);
   a.partial = (zdim > 1) ? (float*)ctx->ws : nullptr;
   // GroupNorm partials from the reduce pass (see igemm_reduce_gn_kernel)
   // ... or the whole GroupNorm from the reduce pass (igemm_reduce_gnapply_kernel)
@@ -1502,7 +1474,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     a.gn_hw = hw_out;
   }
   // LayerNorm row sums of the output for the consumer GEMM (Epi::tile_plain_lnr / the K-split kernels' epilogue)
-  if (d->ln_rows_out && !is_hc && !a.ph_on && zdim == 1 && Epi::plain(a) && !gn_cp && (is_as || is_bt || c.wm * c.wn > 1 || c.nbuf > 0)) {
+  if (d->ln_rows_out && !a.ph_on && zdim == 1 && Epi::plain(a) && !gn_cp && (is_as || is_bt || c.wm * c.wn > 1 || c.nbuf > 0)) {
     // (K-split kernels: one slot per N tile; A-stationary: one per 16 * NI columns of its single pass, else none)
     const int slots = is_as ? (aspl.npass == 1 ? cdiv(a.npad, astat_config_ni(best - kNumCfgs) * 16) : 99)
                             : a.tiles_n * (is_bt ? bt_wn : c.wn);
@@ -1574,8 +1546,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   }
   if (is_as) return astat_launch(ctx, a, best - kNumCfgs, aspl, grid, stream);
   int rc;
-  if (is_hc) rc = hc_launch(ctx, a, best - hc0, hpl, grid, stream);
-  else if (is_bt) rc = bt_launch(ctx, a, best - bt0, grid, stream);
+  if (is_bt) rc = bt_launch(ctx, a, best - bt0, grid, stream);
   else {
   hipLaunchKernelGGL((a.ln_u && !a.lnr_in) ? c.fn_ln : (a.x3 ? c.fn_app : c.fn), grid, dim3(c.nbuf ? 512 : c.wm * c.wn * 64), 0, stream, a);
   rc = upk_check_launch(ctx, "igemm");
@@ -1628,13 +1599,6 @@ extern "C" int upk_conv2d_nhwc_f16(upk_ctx* ctx, const upk_conv_desc* d, upk_str
 extern "C" int upk_conv_ln_rows(upk_ctx* ctx, const upk_conv_desc* d, int* slots) {
   if (!slots) return UPK_EINVAL;
   return conv_impl(ctx, d, nullptr, false, nullptr, nullptr, slots);
-}
-
-extern "C" int upk_conv_gn_input(upk_ctx* ctx, const upk_conv_desc* d, int* ok) {
-  if (!ok) return UPK_EINVAL;
-  *ok = 0;
-  if (!d || !d->gni_stats1) return UPK_OK;
-  return conv_impl(ctx, d, nullptr, false, nullptr, nullptr, nullptr, ok);
 }
 
 extern "C" int upk_conv_gn_fused(upk_ctx* ctx, const upk_conv_desc* d, int* mode, int* nblk) {

@@ -90,15 +90,6 @@ struct IgemmArgs {
   // ---- A-stationary family (astat.hip): a workgroup keeps its BM x K activation tile in LDS and walks passes
   // [tn * as_ppw, min(as_npass, (tn + 1) * as_ppw)) of 8 waves x NI x 16 output columns; tiles_n = N super tiles
   int as_ppw, as_npass;
-  // ---- GroupNorm (+ SiLU) of the INPUT x1 | x2 applied while the halo patch is staged (halo.hip; include/upk.h gni_*):
-  // per-(row block, channel) partial sums of each source, gamma / beta over the concatenated channels
-  const float* gni_st1;
-  const float* gni_st2;
-  int gni_nblk1, gni_ld1, gni_nblk2, gni_ld2;
-  const float* gni_gamma;
-  const float* gni_beta;
-  float gni_eps;
-  int gni_groups, gni_silu;
 };
 
 // Split-K partial slabs ([split][M][n_pad] in the caller's workspace, IgemmArgs::partial).  fp16: the partial sums are
@@ -657,17 +648,5 @@ bool bt_full_epilogue(int c);  // the configuration also exists with the general
 int bt_launch(upk_ctx* ctx, const IgemmArgs& a, int c, dim3 grid, hipStream_t stream);
 
 
-
-// halo.hip: the halo-patch 3x3 family (configurations behind the big-tile ones): input patch resident in LDS, weights
-// streamed into registers by eight waves (4 K slices x 2 N halves); second tuning slot = split-K over channel ranges
-struct HcPlan {
-  int bm, bn, splitk, lds_bytes, cp_off, tab_off;
-  int pw, part_pix, npix, ngrp, cr, nslot, cpt, mps, aps, sh_hw, sh_w, pp_magic, pw_magic;
-  int gni, gni_off;  // input GroupNorm applied by the patch fill; byte offset of its scale / shift scratch
-};
-int hc_num_configs();
-const char* hc_config_name(int c);
-bool hc_plan(const upk_ctx* ctx, const IgemmArgs& a, int c, int splitk, HcPlan* pl);
-int hc_launch(upk_ctx* ctx, const IgemmArgs& a, int c, const HcPlan& pl, dim3 grid, hipStream_t stream);
 
 }  // namespace upkd

@@ -193,14 +193,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a, int rows_
     const int q = tid >> 2, sub = tid & 3;  // q = group*2 + which
     if (q < a.groups * 2) {
       const float* w = a.ws + (long)b * a.nchunks * a.groups * 2 + q;
-      // all (<= 16) partial loads are issued before the first add: a runtime-trip-count
-      // "load, accumulate" loop is compiled into that many DEPENDENT L2 round trips
+      // all (<= 8) partial loads are issued before the first add: a runtime-trip-count "load, accumulate" loop is
+      // compiled into that many DEPENDENT L2 round trips — and so is a conditional load (`idx < n ? w[idx] : 0` became
+      // eight branches, each with its own load + s_waitcnt vmcnt(0)): the loads are unconditional on a clamped index,
+      // the select follows
       float v[GN_MAX_CHUNKS / 4];
 #pragma unroll
       for (int k = 0; k < GN_MAX_CHUNKS / 4; ++k) {
         const int idx = sub + 4 * k;
-        v[k] = idx < a.nchunks ? w[(long)idx * a.groups * 2] : 0.f;
+        v[k] = w[(long)(idx < a.nchunks ? idx : 0) * a.groups * 2];
       }
+#pragma unroll
+      for (int k = 0; k < GN_MAX_CHUNKS / 4; ++k) v[k] = sub + 4 * k < a.nchunks ? v[k] : 0.f;
       double acc = 0.0;
 #pragma unroll
       for (int k = 0; k < GN_MAX_CHUNKS / 4; ++k) acc += (double)v[k];
@@ -284,10 +288,12 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* part, int
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = e0 + u * 256;
-      const int k = e / cpg, c = e - k * cpg;
       const bool on = e < n;
-      v1[u] = on ? p[(long)k * 2 * ld + c] : 0.f;
-      v2[u] = on ? p[(long)k * 2 * ld + ld + c] : 0.f;
+      const int ec = on ? e : 0;  // (unconditional loads on a clamped index: conditional ones serialise, see gn_apply_kernel)
+      const int k = ec / cpg, c = ec - k * cpg;
+      const float t1 = p[(long)k * 2 * ld + c], t2 = p[(long)k * 2 * ld + ld + c];
+      v1[u] = on ? t1 : 0.f;
+      v2[u] = on ? t2 : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {

@@ -103,8 +103,6 @@ UPS_PHASES = os.environ.get("UPGPT_UPS_PHASES", "1") == "1"
 LN_ROWS = os.environ.get("UPGPT_LN_ROWS", "1") == "1"
 QPROJ_FUSE = os.environ.get("UPGPT_QPROJ_FUSE", "1") == "1"
 GN_REDUCE_APPLY = os.environ.get("UPGPT_GN_REDUCE_APPLY", "1") == "1"
-# GroupNorm -> SiLU -> conv3x3 as one launch when the conv's (tuned) configuration is a halo-patch one (include/upk.h gni_*)
-GN_INPUT = os.environ.get("UPGPT_GN_INPUT", "1") == "1"
 # fused feed-forward tail (csrc/mlp.hip: GEGLU -> ff.net.2 o proj_out with the hidden activation in LDS): "auto" = where
 # M / rows-per-workgroup covers the chip (the 32x32 level at B = 8), "0" off, "1" wherever the kernel takes the shape
 MLP_FUSE = os.environ.get("UPGPT_MLP_FUSE", "auto")
@@ -478,12 +476,7 @@ class Emitter:
                       out=out, vt=vt, nchw_out=nchw_out, out_f32=out_f32, spatial=spatial, ln_eps=ln_eps,
                       gn_stats=gn_stats, append=append, lnr=lnr, lnr_alt=lnr_alt)
         if gn is not None:
-            link = {}
-            xn = self.groupnorm(P, x1, *gn[:5], x2=x2, sole=len(gn) > 5 and gn[5], link=link)
-            ret = self.conv(P, xn, pw, **kw_all)
-            if pw.ksize == 3 and stride == 1 and not (flags & (L.F_UPSAMPLE2X | L.F_PAD_ASYM)):
-                link["conv"] = self.convs[-1][0]  # (the GroupNorm op decides, when the program runs, who normalises)
-            return ret
+            return self.conv(P, self.groupnorm(P, x1, *gn[:5], x2=x2, sole=len(gn) > 5 and gn[5]), pw, **kw_all)
         ups = bool(flags & L.F_UPSAMPLE2X)
         HL, WL = (2 * H, 2 * W) if ups else (H, W)
         if flags & L.F_PAD_ASYM:
@@ -642,11 +635,8 @@ class Emitter:
             armed.append((d, act.gn_src[2]))
         return armed
 
-    def groupnorm(self, P, x1, gamma, beta, eps, silu, ws, x2=None, sole=False, link=None):
-        """sole: nothing but this GroupNorm reads x1 (its producer may then skip writing it, see gno_skip_y).
-        link: filled by Emitter.conv with the descriptor of the 3x3 conv that is the only reader of the result — when that
-        launch can normalise its input itself (include/upk.h gni_*: halo-patch configuration, the sources' producers left
-        channel partials) this op hands it the un-normalised sources and launches nothing."""
+    def groupnorm(self, P, x1, gamma, beta, eps, silu, ws, x2=None, sole=False):
+        """sole: nothing but this GroupNorm reads x1 (its producer may then skip writing it, see gno_skip_y)."""
         Cc = x1.C + (x2.C if x2 is not None else 0)
         y = Act(self.alloc(x1.M, Cc), x1.B, x1.H, x1.W, Cc)
         fn, h, chk = self.lib.upk_groupnorm_nhwc_f16, self.hctx, self._chk
@@ -664,7 +654,6 @@ class Emitter:
             # at the time the program runs or is captured
             fused_fn, apply_fn = self.lib.upk_conv_gn_fused, self.lib.upk_groupnorm_apply_nhwc_f16
             fin_fn = self.lib.upk_groupnorm_finalize_f32
-            gni_fn = self.lib.upk_conv_gn_input
             mine = None
             if GN_REDUCE_APPLY and x2 is None and not isinstance(armed[0][0], Emitter.GnProvider) and not armed[0][0].gno_y:
                 # a producer that splits K normalises in its reduce pass (include/upk.h gno_*): this op then launches nothing
@@ -683,25 +672,6 @@ class Emitter:
                     info.append((mode.value if mode.value != 3 or d is mine else 0, nblk.value, d.n_pad, sws.data_ptr()))
                 if len(info) == 1 and info[0][0] == 3:
                     return
-                dc = link.get("conv") if link is not None else None
-                if dc is not None:
-                    if (GN_INPUT and all(i[0] == 2 and 0 < i[1] <= 32 for i in info) and x1.C % 32 == 0
-                            and (x2 is None or x2.C % 32 == 0)):
-                        dc.x1, dc.c1, dc.ld1 = x1.t.data_ptr(), x1.C, x1.ld
-                        if x2 is not None:
-                            dc.x2, dc.c2, dc.ld2 = x2.t.data_ptr(), x2.C, x2.ld
-                            dc.gni_stats2, dc.gni_nblk2, dc.gni_ld2 = info[1][3], info[1][1], info[1][2]
-                        dc.gni_stats1, dc.gni_nblk1, dc.gni_ld1 = info[0][3], info[0][1], info[0][2]
-                        dc.gni_gamma, dc.gni_beta, dc.gni_eps = gamma.data_ptr(), beta.data_ptr(), float(eps)
-                        dc.gni_groups, dc.gni_silu = 32, int(bool(silu))
-                        ok = C.c_int(0)
-                        chk(gni_fn(h, C.byref(dc), C.byref(ok)))
-                        if ok.value:
-                            return
-                    # the conv reads the normalised tensor this op writes
-                    dc.x1, dc.c1, dc.ld1 = y.t.data_ptr(), _rup(Cc, 32), y.ld
-                    dc.x2, dc.c2, dc.ld2 = None, 0, 0
-                    dc.gni_stats1, dc.gni_stats2 = None, None
                 if len(info) == 1 and info[0][0] == 2 and info[0][1] > 32:
                     # long feature maps (VAE decoder): the producer's channel partials are folded per (sample, group)
                     # first — one small launch instead of a statistics pass over the tensor
