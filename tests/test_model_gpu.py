@@ -327,6 +327,26 @@ def test_general_path_equals_fused_path():
     assert mse(x, zn.cpu()) < 1e-5
 
 
+def test_several_steps_per_graph_equal_one_step_per_graph(monkeypatch):
+    """The captured loop runs up to ddim.STEPS_PER_GRAPH steps per graph launch; steps whose result the host looks at
+    (logged intermediates, ddim.py:139-147) end a graph: same latents, same intermediates as one graph per step."""
+    from upgpt_amd import ddim as ddim_mod
+    model, _ = get_model("tiny")
+    inp = inputs("tiny", 2)
+    cond = {"c_crossattn": inp["c_crossattn"].cuda(), "c_concat": [inp["c_concat"].cuda()]}
+    s = DDIMSampler(model)
+    outs = []
+    for n in (1, 4, 8):
+        monkeypatch.setattr(ddim_mod, "STEPS_PER_GRAPH", n)
+        z, inter = s.sample(11, 2, (4, 32, 24), cond, eta=0.0, x_T=inp["x_T"].cuda(), verbose=False, log_every_t=4)
+        outs.append((z, inter))
+    for z, inter in outs[1:]:
+        assert torch.equal(z, outs[0][0])
+        for k in ("x_inter", "pred_x0"):
+            assert len(inter[k]) == len(outs[0][1][k]) == 5  # (x_T, step 0, indices 8, 4, 0)
+            assert all(torch.equal(a, b) for a, b in zip(inter[k], outs[0][1][k]))
+
+
 def test_full_size_properties_b8_50_steps():
     """BASELINE config 2/3 (B=8, 4x32x24, 50-step DDIM): the oracle would need ~90 s here, so
     the full size is checked through properties: bitwise determinism across runs, and

@@ -9,12 +9,17 @@ for all S steps and the cross-attention K/V of the context are computed once bef
 loop.  The reference instead runs ~1-2 k ATen launches plus four torch.full allocations
 per step from Python (ddim.py:140-203).
 """
+import os
+
 import numpy as np
 import torch
 
 from ._check import require
 from .schedule import (ddim_coefficient_table, extract_into_tensor, make_ddim_sampling_parameters,
                        make_ddim_timesteps)
+
+# DDIM steps per HIP graph launch in the captured loop (steps the host watches always end a graph): 1 = a graph per step
+STEPS_PER_GRAPH = max(1, int(os.environ.get("UPGPT_STEPS_PER_GRAPH", "8")))
 
 
 def noise_like(shape, device, repeat=False):
@@ -155,14 +160,22 @@ class DDIMSampler(object):
             plan.prep.run()
             intermediates = {"x_inter": [st.x.clone()], "pred_x0": [st.x.clone()]}
             print(f"Running DDIM Sampling with {S} timesteps")
-            for i in range(S):
-                index = S - i - 1
-                st.launch(with_noise, cfg_scale)
+            # steps whose result the host looks at (callbacks, logged intermediates: ddim.py:139-147) end a graph; the
+            # steps between them run up to STEPS_PER_GRAPH to a graph launch
+            watched = callback is not None or img_callback is not None
+            logged = lambda i: (S - i - 1) % log_every_t == 0 or i == 0
+            i = 0
+            while i < S:
+                n = 1
+                while n < STEPS_PER_GRAPH and i + n < S and not (watched or logged(i + n - 1)):
+                    n += 1
+                st.launch(with_noise, cfg_scale, n)
+                i += n
                 if callback:
-                    callback(i)
+                    callback(i - 1)
                 if img_callback:
-                    img_callback(st.pred_x0.clone(), i)
-                if index % log_every_t == 0 or index == S - 1:
+                    img_callback(st.pred_x0.clone(), i - 1)
+                if logged(i - 1):
                     intermediates["x_inter"].append(st.x.clone())
                     intermediates["pred_x0"].append(st.pred_x0.clone())
             return st.x.clone(), intermediates

@@ -1428,10 +1428,11 @@ class SamplerState:
         self.plan.body.run(s)
         self._emit_tail(s, with_noise, scale)
 
-    def graph(self, with_noise, scale=1.0):
-        """One DDIM step captured as a HIP graph (static shapes, device-side step index; the guidance scale is
-        a kernel argument, so each scale value gets its own graph)."""
-        key = (with_noise, float(scale) if self.cfg else 1.0)
+    def graph(self, with_noise, scale=1.0, nsteps=1):
+        """`nsteps` consecutive DDIM steps captured as ONE HIP graph (static shapes, device-side step index: the same
+        graph serves every position of the loop; the guidance scale is a kernel argument, so each scale value gets its
+        own graph).  nsteps > 1 saves the graph-to-graph launch gap of the steps inside."""
+        key = (with_noise, float(scale) if self.cfg else 1.0) + ((int(nsteps),) if nsteps != 1 else ())
         g = self.graphs.get(key)
         if g is None:
             p = self.plan
@@ -1442,8 +1443,9 @@ class SamplerState:
             sp = side.cuda_stream
             p.ctx._chk(p.lib.upk_graph_begin(p.hctx, sp))
             try:
-                p.body.run(sp)
-                self._emit_tail(sp, with_noise, scale)
+                for _ in range(int(nsteps)):
+                    p.body.run(sp)
+                    self._emit_tail(sp, with_noise, scale)
             finally:
                 gh = C.c_void_p()
                 rc = p.lib.upk_graph_end(p.hctx, sp, C.byref(gh))
@@ -1455,6 +1457,6 @@ class SamplerState:
             g = self.graphs[key] = gh
         return g
 
-    def launch(self, with_noise, scale=1.0):
+    def launch(self, with_noise, scale=1.0, nsteps=1):
         p = self.plan
-        p.ctx._chk(p.lib.upk_graph_launch(p.hctx, self.graph(with_noise, scale), p.ctx._s()))
+        p.ctx._chk(p.lib.upk_graph_launch(p.hctx, self.graph(with_noise, scale, nsteps), p.ctx._s()))
