@@ -407,7 +407,9 @@ int upk_vit_assemble_f16(upk_ctx* ctx, const void* patch_emb, int ld_patch, cons
  * channel concat; output is one [B*HW, c1+c2] fp16 tensor.
  * Replaces GroupNorm32 (util.py:214-216, eps 1e-5), Normalize (attention.py:76-77
  * and model.py:38-39, eps 1e-6) and the following SiLU/swish (openaimodel.py:203,227).
- * stats_ws: fp32 scratch, >= upk_groupnorm_ws_bytes(batch, hw) bytes. */
+ * stats_ws: fp32 scratch, >= upk_groupnorm_ws_bytes(batch, hw) bytes (its contents after the call are unspecified:
+ * feature maps of <= 64 pixels are normalised by ONE launch that keeps a (sample, group) in registers and never
+ * touches it; larger ones by a statistics pass that fills it and an apply pass that reads it). */
 int upk_groupnorm_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* x2, int c2,
                            int ld2, int batch, int hw, int groups, const float* gamma,
                            const float* beta, float eps, int fuse_silu, void* y, int ldy,

@@ -411,8 +411,8 @@ def test_gemm_with_folded_layernorm(ctx, M, d, N, geglu):
 @pytest.mark.parametrize("cin,cout,hw,res", [(896, 896, (8, 8), True), (448, 448, (16, 12), False), (1792, 896, (4, 4), True)])
 def test_splitk_reduce_emits_groupnorm_partials(ctx, cin, cout, hw, res):
     """A split-K conv's reduce pass writes the GroupNorm partial sums of its output (upk_conv_desc.gn_stats_ws):
-    GroupNorm apply-only on them must equal the two-pass GroupNorm bit for bit; without split-K nothing is
-    produced and upk_conv_gn_fused says so."""
+    GroupNorm apply-only on them must equal the two-pass GroupNorm bit for bit (fp16 rounding where the full GroupNorm is
+    the one-launch kernel for small feature maps); without split-K nothing is produced and upk_conv_gn_fused says so."""
     B, (H, W) = 3, hw
     x = rnd(B * H * W, cin).half()
     w = rnd(cout, cin, 3, 3, scale=1 / math.sqrt(9 * cin))
@@ -446,7 +446,10 @@ def test_splitk_reduce_emits_groupnorm_partials(ctx, cin, cout, hw, res):
                                                       gamma.data_ptr(), beta.data_ptr(), 1e-5, 1, app.data_ptr(), cout,
                                                       sws.data_ptr(), 1, 0, n_pad, None, 0, 0, ctx._s()))
         torch.cuda.synchronize()
-        assert torch.equal(full, app)
+        if H * W > 64:
+            assert torch.equal(full, app)
+        else:  # (small feature maps: upk_groupnorm_nhwc_f16 is the one-launch kernel, its sums run in another order)
+            assert (app.float() - full.float()).abs().max().item() <= 2e-3 * full.float().abs().max().item()
     # without split-K: per-(M tile, channel) partials from the epilogue (mode 2) where the tile configuration allows
     # it (M tiles inside one sample, not the K-split kernels), otherwise mode 0 and nothing is promised
     gref = F.silu(F.group_norm(ref.view(B, H * W, cout).permute(0, 2, 1), 32, gamma, beta, 1e-5)).permute(0, 2, 1)
@@ -662,7 +665,13 @@ def test_attention_online_softmax_rescale(ctx):
 
 @pytest.mark.parametrize("c1,c2,hw,silu,eps", [(224, 0, 768, True, 1e-5), (896, 448, 192, True, 1e-5),
                                                (448, 0, 12, False, 1e-6), (128, 0, 4096, True, 1e-6),
-                                               (896, 896, 48, True, 1e-5), (448, 224, 768, True, 1e-5)])
+                                               (896, 896, 48, True, 1e-5), (448, 224, 768, True, 1e-5),
+                                               # small feature maps: one launch (gn_onepass_kernel) — 8-, 4- and 2-wide
+                                               # vectors, groups straddling the concat seam, one value per thread, and
+                                               # odd group widths (two-pass fallback)
+                                               (896, 896, 16, True, 1e-5), (896, 448, 64, True, 1e-5),
+                                               (896, 0, 64, False, 1e-5), (448, 224, 16, True, 1e-6),
+                                               (1024, 1024, 64, True, 1e-5), (32, 0, 4, True, 1e-5), (96, 64, 64, False, 1e-5)])
 def test_groupnorm(ctx, c1, c2, hw, silu, eps):
     B, C = 3, c1 + c2
     xa = (rnd(B, hw, c1) * 2 + 0.5).half()

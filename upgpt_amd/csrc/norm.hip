@@ -12,8 +12,9 @@
 // The input may be a two-source channel concat (openaimodel.py:736): groups may straddle
 // the seam (e.g. 896+448 channels -> 42-wide groups), which the per-channel fold handles.
 // (A single-launch variant — one workgroup per (sample, group set), two passes over its own
-// strided slice — was measured at 21.8 us vs 14.6 us for this pair on the UNet shapes: the
-// 8-byte strided lanes from 64-256 blocks lose to two fully coalesced passes.)
+// strided slice — was measured at 21.8 us vs 14.6 us for this pair on the 16x16 / 32x32 UNet shapes: the
+// 8-byte strided lanes from 64-256 blocks lose to two fully coalesced passes.  At <= 64 pixels per sample the
+// (sample, group) fits the registers of one workgroup and one launch wins: gn_onepass_kernel.)
 #include <stdlib.h>
 
 #include "common.h"
@@ -274,6 +275,83 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a, int rows_
   }
 }
 
+// GroupNorm (+ SiLU) of a SMALL feature map in one launch: grid (groups, batch), a workgroup owns one (sample, group) and
+// keeps its hw * cpg values in registers between the statistics and the normalisation — the 4x4 and 8x8 levels of the
+// UNet, where the concatenated decoder inputs ([h | skip], openaimodel.py:736) have no producer that could leave the
+// statistics as a by-product and the stats + apply pair cost two ~5 us launches for 0.2-0.9 MB.  A thread owns up to NV
+// vectors of V consecutive channels (a vector never straddles the concat seam: c1 % V == 0); per-thread fp32 sums over
+// its <= NV * V values, then fp64 across the workgroup in a fixed order (bitwise reproducible), mean / variance as in
+// gn_apply_kernel.  (At 16x16 and above one workgroup per (sample, group) reads 8-byte strided lanes and loses to the
+// two coalesced passes: see the header.)
+template <int V, int NV>
+__global__ __launch_bounds__(256) void gn_onepass_kernel(const GnArgs a) {
+  typedef f16 hv __attribute__((ext_vector_type(V)));
+  __shared__ double red[8];
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int vpr = a.cpg / V;
+  const int nvec = a.hw * vpr;
+  const int c0 = g * a.cpg;
+  hv x[NV];
+  float gam[NV][V], bet[NV][V];
+  long yoff[NV];
+  bool on[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {  // every load on a clamped index, unconditional (a conditional load is a branch + wait)
+    const int i = tid + k * 256;
+    on[k] = i < nvec;
+    const int ic = on[k] ? i : 0;
+    const int p = ic / vpr;
+    const int c = c0 + (ic - p * vpr) * V;
+    const long pix = (long)b * a.hw + p;
+    const f16* src = c < a.c1 ? a.x1 + pix * a.ld1 + c : a.x2 + pix * a.ld2 + (c - a.c1);
+    x[k] = *(const hv*)src;
+    yoff[k] = pix * a.ldy + c;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      gam[k][j] = a.gamma[c + j];
+      bet[k][j] = a.beta[c + j];
+    }
+  }
+  float s = 0.f, ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float f = on[k] ? (float)x[k][j] : 0.f;
+      s += f;
+      ss += f * f;
+    }
+  double ds = (double)s, dss = (double)ss;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    ds += __shfl_xor(ds, o);
+    dss += __shfl_xor(dss, o);
+  }
+  if ((tid & 63) == 0) {
+    red[(tid >> 6) * 2] = ds;
+    red[(tid >> 6) * 2 + 1] = dss;
+  }
+  __syncthreads();
+  const double n = (double)a.hw * a.cpg;
+  const double mean = (((red[0] + red[2]) + red[4]) + red[6]) / n;
+  double var = (((red[1] + red[3]) + red[5]) + red[7]) / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+  const float fmean = (float)mean;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    hv o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float sc = rstd * gam[k][j];
+      float f = (float)x[k][j] * sc + (bet[k][j] - fmean * sc);
+      if (a.silu) f = upk_silu(f);
+      o[j] = (f16)f;
+    }
+    if (on[k]) *(hv*)(a.y + yoff[k]) = o;
+  }
+}
+
 // Channel partials of a producer conv with many M tiles per sample -> the group partial layout of gn_stats_kernel
 // (chunk 0 holds the totals, the other chunks zero): one workgroup per (sample, group), fixed summation order.
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* part, int nblk, int ld, int cpg, int groups,
@@ -435,6 +513,21 @@ static int gn_launch(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* 
   if (fold1 && a.cp_nblk2 > 1) a.cp_nblk2 = 1;
   upk_prof_scope prof(ctx, UPK_CLS_GN, stream);
   int rc = UPK_OK;
+  // small feature maps: statistics and normalisation in ONE launch (gn_onepass_kernel)
+  static const bool onepass_off = getenv("UPK_GN_ONEPASS") && !atoi(getenv("UPK_GN_ONEPASS"));  // dev: A/B
+  if (with_stats && with_apply && hw <= 64 && !onepass_off) {
+    const int v = !(a.cpg & 7) ? 8 : (!(a.cpg & 3) ? 4 : (!(a.cpg & 1) ? 2 : 0));
+    const int nv = v ? (hw * (a.cpg / v) + 255) / 256 : 0;
+    const dim3 grid(groups, batch);
+    bool done = true;
+    if (v == 8 && nv <= 2) hipLaunchKernelGGL((gn_onepass_kernel<8, 2>), grid, dim3(256), 0, stream, a);
+    else if (v == 8 && nv <= 4) hipLaunchKernelGGL((gn_onepass_kernel<8, 4>), grid, dim3(256), 0, stream, a);
+    else if (v == 4 && nv <= 4) hipLaunchKernelGGL((gn_onepass_kernel<4, 4>), grid, dim3(256), 0, stream, a);
+    else if (v == 4 && nv <= 8) hipLaunchKernelGGL((gn_onepass_kernel<4, 8>), grid, dim3(256), 0, stream, a);
+    else if (v == 2 && nv <= 8) hipLaunchKernelGGL((gn_onepass_kernel<2, 8>), grid, dim3(256), 0, stream, a);
+    else done = false;
+    if (done) return upk_check_launch(ctx, "gn_onepass");
+  }
   if (with_stats) {
     hipLaunchKernelGGL(gn_stats_kernel, dim3(a.nchunks, batch), dim3(256), 0, stream, a);
     rc = upk_check_launch(ctx, "gn_stats");
