@@ -548,9 +548,11 @@ static int attention_impl(upk_ctx* ctx, const void* q, int ldq, long long qbs, c
   a.scale_log2 = scale * 1.4426950408889634f;
   a.causal = causal;
   if (causal && n_q != n_kv) return upk_fail(ctx, UPK_EINVAL, "attention: causal needs n_q == n_kv");
-  // two 16-query groups per wave when there are enough queries to keep every CU busy
+  // two 16-query groups per wave when there are enough queries to give every CU four workgroups even so (at two per CU —
+  // the 32x32 level at B = 8: 512 workgroups of 128 queries — the single-group form with its 1024 workgroups hides the
+  // K / V tile latency better: 22 -> 17.6 us per launch, forward 2.890 -> 2.867 ms, same-box A/B of UPK_ATTN_QT)
   static const int qt_env = getenv("UPK_ATTN_QT") ? atoi(getenv("UPK_ATTN_QT")) : 0;  // dev
-  const int qt = qt_env ? qt_env : ((d <= 128 && (long)((n_q + 127) / 128) * batch * heads >= 2L * ctx->num_cus) ? 2 : 1);
+  const int qt = qt_env ? qt_env : ((d <= 128 && (long)((n_q + 127) / 128) * batch * heads >= 4L * ctx->num_cus) ? 2 : 1);
   // grid.x = (sample, head): workgroups go to XCDs round-robin by linear index, so with batch * heads a multiple of 8
   // every query block of a (sample, head) lands on the same XCD and K / V are fetched over the fabric once, not 8 times
   dim3 grid(batch * heads, (n_q + 64 * qt - 1) / (64 * qt)), block(256);
