@@ -550,7 +550,7 @@ static int attention_impl(upk_ctx* ctx, const void* q, int ldq, long long qbs, c
   if (causal && n_q != n_kv) return upk_fail(ctx, UPK_EINVAL, "attention: causal needs n_q == n_kv");
   // two 16-query groups per wave when there are enough queries to give every CU four workgroups even so (at two per CU —
   // the 32x32 level at B = 8: 512 workgroups of 128 queries — the single-group form with its 1024 workgroups hides the
-  // K / V tile latency better: 22 -> 17.6 us per launch, forward 2.890 -> 2.867 ms, same-box A/B of UPK_ATTN_QT)
+  // K / V tile latency better: forward 2.890 -> 2.867 ms, -4.5 us per launch in situ, same-box A/B of UPK_ATTN_QT)
   static const int qt_env = getenv("UPK_ATTN_QT") ? atoi(getenv("UPK_ATTN_QT")) : 0;  // dev
   const int qt = qt_env ? qt_env : ((d <= 128 && (long)((n_q + 127) / 128) * batch * heads >= 4L * ctx->num_cus) ? 2 : 1);
   // grid.x = (sample, head): workgroups go to XCDs round-robin by linear index, so with batch * heads a multiple of 8
