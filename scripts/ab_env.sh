@@ -4,7 +4,7 @@
 R=$GRAFT_REPO_ROOT; cd $R
 VAR=$1; shift
 for v in "$@" "$@"; do
-  env $VAR=$v AB_VAR=$VAR python - <<'PY' 2>/dev/null | tail -1
+  env $VAR=$v AB_VAR=$VAR timeout 300 python - <<'PY' 2>/dev/null | tail -1
 import contextlib, io, os, sys, time, torch
 sys.path.insert(0, os.getcwd())
 import upgpt_amd
