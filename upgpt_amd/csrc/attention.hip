@@ -178,8 +178,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   const int wave = threadIdx.x >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int bh = blockIdx.x;  // (all query blocks of one (sample, head) on one XCD: its K / V cross the fabric once)
+#ifndef UPK_NO_XCD_SAMPLE
+  const int nb_ = gridDim.x / a.heads;
+  const int b = bh % nb_;
+  const int h = bh / nb_;
+#else
   const int b = bh / a.heads;
   const int h = bh - b * a.heads;
+#endif
   const int q0 = (blockIdx.y * (blockDim.x >> 6) + wave) * 16 * QT;  // (1, 2 or 4 waves per workgroup: no wave talks to another)
   if (q0 >= a.nq) return;
   const f16* kbase = a.k + b * a.kbs + h * D + g * 8;
@@ -385,8 +391,14 @@ __global__ __launch_bounds__(256) void attn_lds_kernel(const AttnArgs a) {
   const int lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
   const int bh = blockIdx.x;  // (see attn_kernel)
+#ifndef UPK_NO_XCD_SAMPLE
+  const int nb_ = gridDim.x / a.heads;
+  const int b = bh % nb_;
+  const int h = bh / nb_;
+#else
   const int b = bh / a.heads;
   const int h = bh - b * a.heads;
+#endif
   const int q0 = (blockIdx.y * 4 + wave) * 16 * QT;
   const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 

@@ -119,6 +119,31 @@ static inline int upk_check_launch(upk_ctx* ctx, const char* what) {
   return UPK_OK;
 }
 
+// Workgroup -> work-item orders that keep a SAMPLE on one XCD (workgroup w runs on XCD w % 8): with the batch a multiple
+// of 8, the row-chain kernels (xblock.hip, mlp.hip), the attention kernels, the GroupNorm apply / one-launch kernels and
+// the normalising reduce passes all work on sample b from XCD b % 8, so each finds what its predecessor wrote for that
+// sample in the local L2 instead of on the memory side of the fabric: forward 2.862 -> 2.844 ms (same-box A/B of the two
+// builds).  The conv / GEMM launches keep their own XCD map (igemm.hip: fabric bytes of weights against
+// activations; forcing the sample order on them costs +11 .. +110 us).  -DUPK_NO_XCD_SAMPLE: the plain orders (A/B builds).
+__device__ __forceinline__ int upk_xcd_tile(int w, int n) {  // tile of workgroup w out of n row tiles in sample order
+#ifndef UPK_NO_XCD_SAMPLE
+  return (n & 7) ? w : (w & 7) * (n >> 3) + (w >> 3);
+#else
+  (void)n;
+  return w;
+#endif
+}
+// grid (nx, batch): (x, sample) of this workgroup
+__device__ __forceinline__ void upk_xcd_xb(int& x, int& b) {
+#ifndef UPK_NO_XCD_SAMPLE
+  const int L = blockIdx.x + gridDim.x * blockIdx.y;
+  b = L % (int)gridDim.y;
+  x = L / (int)gridDim.y;
+#else
+  x = blockIdx.x;
+  b = blockIdx.y;
+#endif
+}
 // (v_rcp_f32, 1 ulp, instead of an IEEE division: the ~10-instruction div sequence per element was most of the VALU
 // work of the GroupNorm apply passes; results are rounded to fp16 right after)
 __device__ __forceinline__ float upk_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }

@@ -931,7 +931,9 @@ template <int V, int NV>
 __global__ __launch_bounds__(256) void igemm_reduce_gnapply_kernel(const IgemmArgs a, int splitk, const GnApply g) {
   using IO = VecIO<V>;
   __shared__ double red[8];
-  const int grp = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  int grp, b;
+  upk_xcd_xb(grp, b);
+  const int tid = threadIdx.x;
   const int vpr = g.cpg / V;
   const int nvec = g.hw * vpr;
   const int c0 = grp * g.cpg;
@@ -1031,7 +1033,8 @@ __global__ __launch_bounds__(256) void igemm_reduce_gn_kernel(const IgemmArgs a,
   __shared__ float sc[2][256 * 8];
   const int C = a.n_out;
   const int vpr = C >> 3;
-  const int b = blockIdx.y, chunk = blockIdx.x;
+  int chunk, b;
+  upk_xcd_xb(chunk, b);
   const int tid = threadIdx.x;
   const int p0 = chunk * gf.pix_per_chunk;
   const int p1 = min(gf.hw, p0 + gf.pix_per_chunk);

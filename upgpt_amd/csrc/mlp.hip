@@ -59,7 +59,7 @@ __global__ __launch_bounds__(512) void mlp_kernel(const MlpArgs s) {
 #define STAMP(i) do { } while (0)
 #endif
   STAMP(0);
-  const int m0 = blockIdx.x * BM;
+  const int m0 = upk_xcd_tile(blockIdx.x, gridDim.x) * BM;
   const int nch1 = s.nch1, nh = s.nh, nch2 = nh + nch1;
   // LDS: chunks [0, nh) = h, chunks [nh, nh + nch1) = t2  (the second GEMM's K order), then the row statistics
   f16* const hT = smem;

@@ -125,12 +125,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a, int rows_
   extern __shared__ __attribute__((aligned(16))) float tab[];  // scale[C], shift[C]
   __shared__ float smean[GN_GROUPS_MAX], srstd[GN_GROUPS_MAX];
   const int C = a.c1 + a.c2;
-  const int b = blockIdx.y;
+  int bx, b;
+  upk_xcd_xb(bx, b);
   const int tid = threadIdx.x;
   // issue this thread's first x vectors NOW: their latency overlaps the statistics /
   // table work below instead of forming a third dependent memory round trip
   const int vpr = C >> 3;
-  const int p0 = blockIdx.x * rows_per_block;
+  const int p0 = bx * rows_per_block;
   const int p1 = min(a.hw, p0 + rows_per_block);
   const int nvec = (p1 - p0) * vpr;
   f16x8 pre[GN_PREF];
@@ -287,7 +288,9 @@ template <int V, int NV>
 __global__ __launch_bounds__(256) void gn_onepass_kernel(const GnArgs a) {
   typedef f16 hv __attribute__((ext_vector_type(V)));
   __shared__ double red[8];
-  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  int g, b;
+  upk_xcd_xb(g, b);
+  const int tid = threadIdx.x;
   const int vpr = a.cpg / V;
   const int nvec = a.hw * vpr;
   const int c0 = g * a.cpg;

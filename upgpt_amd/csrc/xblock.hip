@@ -136,7 +136,7 @@ __global__ __launch_bounds__(512) void xblock_kernel(const XbArgs s) {
 #define STAMP(i) do { } while (0)
 #endif
   STAMP(0);
-  const int m0 = blockIdx.x * BM;
+  const int m0 = upk_xcd_tile(blockIdx.x, gridDim.x) * BM;
   const int b = m0 / s.hw;  // (hw % BM == 0: a workgroup never straddles two samples)
   f16* const aT = smem;                                // [NCHD][BM][32]  a1, later a2
   f16* const tT = smem + NCHD * BM * 32;               // [C32][BM][32]   t1
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(512) void hblock_kernel(const HbArgs s) {
 #define STAMP(i) do { } while (0)
 #endif
   STAMP(0);
-  const int m0 = blockIdx.x * BM;
+  const int m0 = upk_xcd_tile(blockIdx.x, gridDim.x) * BM;
   const int b = m0 / s.hw;
   const int tok0 = m0 - b * s.hw;
   f16* const aT = smem;                            // [C32][BM][32]  xn (x until the GroupNorm is applied in place)
