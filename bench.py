@@ -32,6 +32,12 @@ PEAK_MFMA_F16_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_TBS = 8.0             # spec (6.3 TB/s measured for a float4 copy), same guide
 
 
+def torchrun_command(n, argv, port):
+    """The command line `python bench.py --gpus N` becomes: one rank per GPU on this node, rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+            "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def relaunch_under_torchrun(n, argv):
     """`python bench.py --gpus N` with no rendezvous in the environment: become
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`."""
@@ -39,8 +45,7 @@ def relaunch_under_torchrun(n, argv):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    cmd = torchrun_command(n, argv, port)
     print("[bench] launching %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
     os.execv(sys.executable, cmd)
 
@@ -484,7 +489,7 @@ def main():
     synth.fill_module_(model)
     model = model.cuda()
     log("[bench] rank %d model ready in %.1fs" % (rank, time.time() - t0))
-    wl = Workload(model, args.batch, hw, args.ddim_steps, seed=rank)
+    wl = Workload(model, args.batch, hw, args.ddim_steps, seed=D.rank_seed(0, rank))
 
     step = gathered(lambda: quiet(wl.run))
 

@@ -120,3 +120,46 @@ def test_bench_self_launches_its_ranks_and_fails_only_for_lack_of_gpus():
     assert "launching 2 ranks" in err and "torch.distributed.run" in err
     assert "needs an MI355X per rank" in err
     assert "AssertionError" not in err and r.returncode != 0
+
+
+def test_numa_cpulist_and_pinning_lookup(tmp_path):
+    """a rank is pinned to the CPUs of its GPU's NUMA node; the sysfs lookup on a fake tree."""
+    assert D.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert D.parse_cpulist("") == []
+    dev = tmp_path / "bus" / "pci" / "devices" / "0000:c1:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    node = tmp_path / "devices" / "system" / "node" / "node1"
+    node.mkdir(parents=True)
+    (node / "cpulist").write_text("64-127,192-255\n")
+    cpus = D.gpu_numa_cpus("0000:C1:00.0", sysfs=str(tmp_path))
+    assert cpus[0] == 64 and cpus[-1] == 255 and len(cpus) == 128
+    (dev / "numa_node").write_text("-1\n")
+    assert D.gpu_numa_cpus("0000:c1:00.0", sysfs=str(tmp_path)) is None  # (the kernel does not know: no pinning)
+    assert D.gpu_numa_cpus("0000:ff:00.0", sysfs=str(tmp_path)) is None
+    assert D.pin_to_gpu_numa(0, sysfs=str(tmp_path)) is None  # (no GPU here / unknown node: a no-op, never an error)
+
+
+def test_bench_builds_the_eight_rank_command_and_per_rank_seeds():
+    """`python bench.py --gpus 8` re-launches itself as ONE torchrun command with eight ranks on 127.0.0.1 (the
+    driver's contract), and rank r draws its x_T / conditioning from seed + r."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    argv = ["--gpus", "8", "--steps", "5", "--warmup", "2"]
+    cmd = bench.torchrun_command(8, argv, 29511)
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    i = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[i + 1:] == argv
+    assert [D.rank_seed(0, r) for r in range(8)] == list(range(8))
+    # different ranks really get different latents, the same rank the same ones
+    from upgpt_amd import synth
+    a = synth.synth_inputs(2, (8, 8), 4, 87, 768, seed=D.rank_seed(0, 0), text_only=True)["x_T"]
+    b = synth.synth_inputs(2, (8, 8), 4, 87, 768, seed=D.rank_seed(0, 1), text_only=True)["x_T"]
+    a2 = synth.synth_inputs(2, (8, 8), 4, 87, 768, seed=D.rank_seed(0, 0), text_only=True)["x_T"]
+    assert torch.equal(a, a2) and not torch.equal(a, b)

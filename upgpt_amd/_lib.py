@@ -28,6 +28,7 @@ SYMBOLS = [
     "upk_patchify_nchw_f32_f16", "upk_vit_assemble_f16", "upk_gather_rows_f16",
     "upk_advance_step", "upk_step_autoadvance", "upk_kernel_launches", "upk_graph_begin", "upk_graph_end", "upk_graph_launch", "upk_graph_destroy",
     "upk_prof_enable", "upk_prof_collect",
+    "upk_xcd_sync_bytes", "upk_xcd_phase_check", "upk_xcd_run_f16", "upk_xcd_status",
 ]
 
 F_SILU, F_GEGLU, F_OUT_F32, F_OUT_NCHW_F32, F_UPSAMPLE2X, F_PAD_ASYM = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
@@ -102,6 +103,29 @@ class HblockDesc(C.Structure):
         ("vt", C.c_void_p), ("vt_ld", C.c_int32), ("hw", C.c_int32), ("rows_per_wg", C.c_int32),
         ("gn_part", C.c_void_p), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p),
         ("gn_nblk", C.c_int32), ("gn_ld", C.c_int32), ("gn_groups", C.c_int32), ("gn_eps", C.c_float),
+    ]
+
+
+XP_GN, XP_GEMM, XP_ATTN = 1, 2, 3
+XE_PLAIN, XE_GEGLU, XE_QKV = 0, 1, 2
+
+
+class XPhase(C.Structure):
+    """Mirror of struct upk_xphase (include/upk.h): one phase of the per-XCD engine."""
+    _fields_ = [
+        ("kind", C.c_int32), ("n", C.c_int32),
+        ("a", C.c_void_p), ("a2", C.c_void_p),
+        ("lda", C.c_int32), ("lda2", C.c_int32), ("k1", C.c_int32), ("k2", C.c_int32),
+        ("w", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p), ("y", C.c_void_p), ("vt", C.c_void_p),
+        ("ntiles", C.c_int32), ("n_out", C.c_int32), ("ldres", C.c_int32), ("ldy", C.c_int32),
+        ("epi", C.c_int32), ("ln", C.c_int32), ("eps", C.c_float), ("vtile0", C.c_int32),
+        ("vt_ld", C.c_int32), ("heads", C.c_int32), ("dp", C.c_int32), ("pm", C.c_int32),
+        ("pn", C.c_int32), ("mb", C.c_int32), ("tn", C.c_int32), ("groups", C.c_int32),
+        ("kk", C.c_void_p), ("vv", C.c_void_p),
+        ("ldk", C.c_int32), ("koff", C.c_int32), ("nkv", C.c_int32), ("silu", C.c_int32),
+        ("kbs", C.c_longlong), ("vbs", C.c_longlong),
+        ("scale_log2", C.c_float), ("pad0", C.c_int32),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p),
     ]
 
 
@@ -181,6 +205,10 @@ def load_library(path=None):
             "upk_graph_destroy": (C.c_int, [vp, vp]),
             "upk_prof_enable": (C.c_int, [vp, i32]),
             "upk_prof_collect": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+            "upk_xcd_sync_bytes": (C.c_size_t, []),
+            "upk_xcd_phase_check": (C.c_int, [vp, C.POINTER(XPhase)]),
+            "upk_xcd_run_f16": (C.c_int, [vp, vp, i32, i32, vp, vp]),
+            "upk_xcd_status": (C.c_int, [vp, vp, C.POINTER(C.c_int)]),
         }
         require(sorted(protos) == sorted(SYMBOLS), "ctypes prototypes and SYMBOLS differ", RuntimeError)
         for name, (res, args) in protos.items():

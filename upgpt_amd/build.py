@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.environ.get("UPK_LIB") or os.path.join(HERE, "libupk.so")  # (UPK_LIB + UPK_CXXFLAGS: dev builds)
-SOURCES = ["igemm.hip", "bigtile.hip", "astat.hip", "mlp.hip", "xblock.hip", "attention.hip", "norm.hip", "misc.hip"]
+SOURCES = ["igemm.hip", "bigtile.hip", "astat.hip", "mlp.hip", "xblock.hip", "attention.hip", "norm.hip", "misc.hip", "xcd.hip"]
 # per-file flags.  attention.hip: MFMA results straight into arch VGPRs — the softmax between the two matmuls reads
 # every score with VALU instructions, and with the accumulators in AGPRs 112 of ~600 issue slots per 64-key tile were
 # v_accvgpr moves (the kernels use < 128 registers, there is nothing to gain from the AGPR file)
@@ -67,8 +67,26 @@ def build(force=False, verbose=True):
              "-Wno-unused-result", "-I", os.path.join(HERE, "..", "include")]
     flags += os.environ.get("UPK_CXXFLAGS", "").split()  # dev builds, e.g. -DUPK_TIMELINE (scripts/timeline.py)
 
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [
+        os.path.join(HERE, "..", "include", "upk.h")]
+
+    def obj_hash(src):  # an object is reused only when its source, every header and its flags are unchanged
+        h = hashlib.sha256()
+        for path in [os.path.join(CSRC, src)] + headers:
+            with open(path, "rb") as f:
+                h.update(f.read())
+        h.update(repr(flags + FILE_FLAGS.get(src, [])).encode())
+        return h.hexdigest()
+
     def cc(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        want = obj_hash(src)
+        try:
+            with open(obj + ".sha256") as f:
+                if not force and os.path.exists(obj) and f.read().strip() == want and os.environ.get("UPK_FORCE_BUILD", "0") != "1":
+                    return obj
+        except OSError:
+            pass
         cmd = [hipcc] + flags + FILE_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print("[upgpt_amd.build]", " ".join(cmd), flush=True)
@@ -77,6 +95,8 @@ def build(force=False, verbose=True):
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
+        with open(obj + ".sha256", "w") as f:
+            f.write(want + "\n")
         return obj
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:

@@ -18,10 +18,65 @@ def env_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
+def parse_cpulist(text):
+    """'0-3,8,10-11' (sysfs cpulist syntax) -> sorted list of CPU numbers."""
+    cpus = set()
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return sorted(cpus)
+
+
+def gpu_numa_cpus(pci_bus_id, sysfs="/sys"):
+    """CPUs of the NUMA node the GPU at `pci_bus_id` ("0000:c1:00.0") hangs off, from sysfs, or None when the kernel
+    does not say (numa_node = -1, no such device, container without /sys)."""
+    try:
+        with open(os.path.join(sysfs, "bus", "pci", "devices", pci_bus_id.lower(), "numa_node")) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        with open(os.path.join(sysfs, "devices", "system", "node", "node%d" % node, "cpulist")) as f:
+            cpus = parse_cpulist(f.read())
+        return cpus or None
+    except (OSError, ValueError):
+        return None
+
+
+def pin_to_gpu_numa(local_rank, sysfs="/sys"):
+    """Restricts this process (one rank = one GPU) to the CPUs of its GPU's NUMA node: at N = 8 the eight host
+    threads that replay graphs, and RCCL's proxy threads, otherwise migrate across sockets and the launch path of a
+    rank crosses the inter-socket link.  Intersected with the CPUs the process may use already (cgroup / taskset);
+    a no-op (returns None) when the topology cannot be read or the intersection is empty.  Returns the CPU list."""
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        bus = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    except Exception:
+        return None
+    cpus = gpu_numa_cpus(bus, sysfs)
+    if not cpus or not hasattr(os, "sched_setaffinity"):
+        return None
+    allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+    if not allowed:
+        return None
+    os.sched_setaffinity(0, allowed)
+    return allowed
+
+
+def rank_seed(seed, rank):
+    """Seed of rank `rank`'s x_T / synthetic inputs (seed + rank; conditioning follows the same seed)."""
+    return int(seed) + int(rank)
+
+
 def init_from_env(backend=None):
     """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* when WORLD_SIZE > 1.
-    backend: "nccl" (= RCCL) on GPUs, "gloo" for the CPU tests."""
+    backend: "nccl" (= RCCL) on GPUs, "gloo" for the CPU tests.  With world > 1 on GPUs the rank is first pinned to
+    its GPU's NUMA node (UPGPT_NUMA_PIN=0 switches that off)."""
     rank, local_rank, world = env_world()
+    if world > 1 and torch.cuda.is_available() and os.environ.get("UPGPT_NUMA_PIN", "1") == "1":
+        pin_to_gpu_numa(local_rank)
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"

@@ -114,6 +114,12 @@ XB_ROWS = int(os.environ.get("UPGPT_XB_ROWS", "0"))  # rows per workgroup (16 / 
 # fused head of a SpatialTransformer (csrc/xblock.hip hblock_kernel: proj_in -> norm1 -> q | k | v, one launch instead of two)
 HBLOCK = os.environ.get("UPGPT_HBLOCK", "auto")
 HBLOCK_GN = os.environ.get("UPGPT_HBLOCK_GN", "1") == "1"  # SpatialTransformer.norm applied on the tile inside that launch
+# per-XCD persistent engine (csrc/xcd.hip, include/upk.h upk_xcd_run_f16): a whole SpatialTransformer as ONE launch, sample b
+# on XCD b % 8.  "auto" = batches that are a multiple of 8 at feature maps of <= XCD_MAXN pixels, "1" wherever the engine
+# takes the shape (any batch: tests), "0" off.  UPGPT_XCD_SPLIT=1: one launch per phase (debugging aid).
+XCD = os.environ.get("UPGPT_XCD", "auto")
+XCD_MAXN = int(os.environ.get("UPGPT_XCD_MAXN", "256"))
+XCD_SPLIT = os.environ.get("UPGPT_XCD_SPLIT", "0") == "1"
 LN_LAUNCH_US = 5.0  # what a separate LayerNorm launch costs inside the replayed forward (3.8 us of kernel + its boundary: DESIGN.md 11i / 11j)
 
 
@@ -145,6 +151,11 @@ class Act:
 class PW:
     """A packed weight: fp16 tiles + fp32 bias in packed row order."""
     __slots__ = ("w", "n_pad", "bias", "n_out", "k_packed", "ksize", "n_real", "k_real", "ln_colsum", "k_append", "w_phase")
+
+
+class PWX:
+    """A weight packed for the per-XCD engine (Packer.pack_xcd)."""
+    __slots__ = ("w", "bias", "ntiles", "k", "n")
 
 
 class Packer:
@@ -255,6 +266,39 @@ class Packer:
     def vec(self, name):
         return self.get(name).float().contiguous()
 
+    def pack_xcd(self, w, bias=None, rows=None, cols=None):
+        """[N, K] fp32 -> operands of a upk_xphase GEMM (include/upk.h): fp16 tiles [N/16][K/32][64 lanes][8] (lane
+        16 g + i holds W[16 t + i][32 kc + 8 g .. + 7]) and the fp32 bias in tile order, N padded to 16 and K to 32 with
+        zeros.  rows / cols: index tensors (packed row / column <- source row / column, -1 = zero), applied first."""
+        w = w.float().to(self.dev)
+        if rows is not None:
+            r = torch.as_tensor(rows, device=self.dev).long()
+            wr = w.new_zeros(r.numel(), w.shape[1])
+            wr[r >= 0] = w[r[r >= 0]]
+            if bias is not None:
+                br = w.new_zeros(r.numel())
+                br[r >= 0] = bias.float().to(self.dev)[r[r >= 0]]
+                bias = br
+            w = wr
+        if cols is not None:
+            c = torch.as_tensor(cols, device=self.dev).long()
+            wc = w.new_zeros(w.shape[0], c.numel())
+            wc[:, c >= 0] = w[:, c[c >= 0]]
+            w = wc
+        N, K = w.shape
+        N16, K32 = _rup(N, 16), _rup(K, 32)
+        wp = w.new_zeros(N16, K32)
+        wp[:N, :K] = w
+        T, KC = N16 // 16, K32 // 32
+        px = PWX()
+        px.w = wp.half().view(T, 16, KC, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+        px.bias = None
+        if bias is not None:
+            px.bias = w.new_zeros(N16)
+            px.bias[:N] = bias.float().to(self.dev)
+        px.ntiles, px.k, px.n = T, K32, N
+        return px
+
 
 def qproj_pack(w, gamma, beta, heads, dh, dp, cq, dev):
     """to_q weight [heads*dh, C] (+ the LayerNorm affine in front of it) -> operands of upk_attention_qproj_f16
@@ -346,6 +390,8 @@ class Emitter:
             ent = cache.get(key)
             if ent is None and not tune_missing and key.endswith("_gs"):
                 ent = cache.get(key[:-3])  # (statistics by-product armed on a shape that was tuned without it)
+            if ent is None and not tune_missing and not key.endswith("_gs"):
+                ent = cache.get(key + "_gs")  # (tuned with the statistics by-product armed; the choice is valid without)
             if ent is None and not tune_missing and key.endswith("_lnr"):
                 ent = cache.get(key[:-4])  # (tuned as a plain GEMM; usable only if that choice does not split K)
                 if ent is not None and int(ent[1]) != 1 and not self._is_as(int(ent[0])):
@@ -948,6 +994,8 @@ class PackedUNet:
                 # transformer's output projection as one GEMM with t2 as an appended K segment (Emitter.fold_ff_out)
                 w[n + ".ff.out+proj_out"] = pk.append_1x1(pk.pack_product(n + ".proj_out", t + ".ff.net.2"),
                                                           w[n + ".proj_out"])
+                if XCD != "0" and 32 % heads == 0 and dp in (32, 64, 128) and Lr.ch % 32 == 0:
+                    w[n + ".xcd"] = self._pack_xcd_block(pk, get, n, t, Lr, heads, dh, dp)
             elif Lr.kind == "down":
                 w[n + ".op"] = pk.pack(n + ".op")
             elif Lr.kind == "up":
@@ -955,6 +1003,83 @@ class PackedUNet:
         norm("out.0")
         w["out.2"] = pk.pack("out.2")
         self.w, self.v = w, v
+
+
+def _pack_xcd_block(self, pk, get, n, t, Lr, heads, dh, dp):
+    """The seven GEMMs of a SpatialTransformer as per-XCD engine operands (include/upk.h upk_xphase).  Every norm in front
+    of a Linear is folded into it: W' = W * gamma (per input column), b' = b + W beta — SpatialTransformer.norm
+    (attention.py:254) into proj_in, norm1 / norm2 / norm3 (attention.py:212-215) into q|k|v, attn2.to_q and the GEGLU
+    projection; the engine's GroupNorm / LayerNorm then only subtract the mean and scale by rstd."""
+    f = lambda name: get(name).float().to(pk.dev)
+    C_ = Lr.ch
+    inner = 4 * heads * dh
+
+    def folded(wname, gname, bias=None):
+        W = f(wname + ".weight")
+        W = W.reshape(W.shape[0], -1)
+        b = W @ f(gname + ".bias")
+        if bias is not None:
+            b = b + f(bias)
+        return W * f(gname + ".weight")[None, :], b
+
+    o = {}
+    Wi, bi = folded(n + ".proj_in", n + ".norm", n + ".proj_in.bias")
+    o["proj_in"] = pk.pack_xcd(Wi, bi)
+    Wq = torch.cat([f(t + ".attn1.to_q.weight"), f(t + ".attn1.to_k.weight"), f(t + ".attn1.to_v.weight")], 0)
+    g1, b1 = f(t + ".norm1.weight"), f(t + ".norm1.bias")
+    o["qkv"] = pk.pack_xcd(Wq * g1[None, :], Wq @ b1, rows=pad_rows_map(3, heads, dh, dp))
+    hcols = pad_rows_map(1, heads, dh, dp)
+    o["out1"] = pk.pack_xcd(f(t + ".attn1.to_out.0.weight"), f(t + ".attn1.to_out.0.bias"), cols=hcols)
+    W2, b2 = folded(t + ".attn2.to_q", t + ".norm2")
+    o["q2"] = pk.pack_xcd(W2, b2, rows=hcols)
+    o["out2"] = pk.pack_xcd(f(t + ".attn2.to_out.0.weight"), f(t + ".attn2.to_out.0.bias"), cols=hcols)
+    Wg, bg = folded(t + ".ff.net.0.proj", t + ".norm3", t + ".ff.net.0.proj.bias")
+    u = torch.arange(2 * inner)
+    tile, i = u // 16, u % 16
+    grows = torch.where(tile % 2 == 0, (tile // 2) * 16 + i, inner + (tile // 2) * 16 + i)  # tiles alternate value / gate
+    o["geglu"] = pk.pack_xcd(Wg, bg, rows=grows)
+    # proj_out(t2 + ff.net.2(h)) + x = (P F2) h + P t2 + (P b2 + bp) + x: one GEMM over [h | t2]
+    Pw = f(n + ".proj_out.weight")
+    Pw = Pw.reshape(Pw.shape[0], -1)
+    F2, c2 = f(t + ".ff.net.2.weight"), f(t + ".ff.net.2.bias")
+    o["ffout"] = pk.pack_xcd(torch.cat([Pw @ F2, Pw], 1), Pw @ c2 + f(n + ".proj_out.bias"))
+    o["inner"] = inner
+    return o
+
+
+PackedUNet._pack_xcd_block = _pack_xcd_block
+
+
+def xcd_gemm_grid(n, ntiles, K, pair=False, lds_bytes=152 * 1024 - 64):
+    """(pm, pn, mb, tn) of a per-XCD engine GEMM: the XCD's 32 CUs as a pm x pn grid of (mb rows) x (ntiles / pn column
+    tiles), tn tiles per wave pass.  Cost model in CU cycles: staging of the CU's rows (L2 -> registers -> LDS) +
+    max(weight stream into the CU at ~40 B / clk, MFMA issue at 4 SIMDs x one 16x16x32 per 17 clk, LDS fragment reads at
+    256 B / clk), the serial chain of the busiest wave on top.  pair: tiles come in (value, gate) / q|k|v pairs."""
+    KC = (K + 31) // 32
+    Kpad = _rup(K, 128)
+    best = None
+    for pm in (1, 2, 4, 8, 16, 32):
+        mb = _rup((n + pm - 1) // pm, 16)
+        if mb > 64 or mb * (Kpad * 2 + 32) > lds_bytes:
+            continue
+        pm_eff = (n + mb - 1) // mb
+        pn = max(1, min(32 // pm_eff, ntiles // 2 if pair else ntiles))
+        tpc = (ntiles + pn - 1) // pn
+        if pair and tpc % 2:
+            tpc += 1
+        tm = mb // 16
+        for tn in ((2,) if pair else (1, 2)):
+            units = (tpc + tn - 1) // tn
+            rounds = (units + 7) // 8
+            stage = mb * Kpad * 2 / 30.0
+            fill = tpc * 16 * K * 2 / 40.0
+            mfma = tm * tpc * KC * 17 / 4.0
+            ldsr = tm * units * KC * 4.0
+            chain = rounds * KC * (tm * tn * 17 + 40)
+            cost = stage + max(fill, mfma, ldsr, chain)
+            if best is None or cost < best[0]:
+                best = (cost, pm_eff, pn, mb, tn)
+    return None if best is None else best[1:]
 
 
 class UNetPlan(Emitter):
@@ -1047,9 +1172,116 @@ class UNetPlan(Emitter):
             sk = x
         return self.conv(P, hh, w[n + ".out_layers.3"], residual=sk, gn=gn2, gn_stats=True)
 
+    def xcd_block(self, P, Lr, x):
+        """The whole SpatialTransformer (attention.py:250-261) as ONE launch of the per-XCD engine (include/upk.h
+        upk_xcd_run_f16; csrc/xcd.hip): GroupNorm -> proj_in -> [LN1 -> q|k|v -> self-attention -> to_out + t0] ->
+        [LN2 -> to_q -> attention over the precomputed context K / V -> to_out + t1] -> [LN3 -> GEGLU] ->
+        ff.net.2 o proj_out + x: ten phases, XCD-local barriers between them.  Returns the output Act, or None when the
+        engine is off / does not take the shape (the caller then emits the launch chain)."""
+        n = Lr.name
+        wx = self.pk.w.get(n + ".xcd")
+        if XCD == "0" or wx is None or n not in self.kv:
+            return None
+        B, HW, M, C_ = x.B, x.H * x.W, x.M, x.C
+        if XCD != "1" and (B % 8 or HW > XCD_MAXN):
+            return None
+        if x.ld != C_ or HW % 4 or self.ctx.num_cus != 256:
+            return None
+        heads, dh = Lr.heads, Lr.dhead
+        dp = head_pad(dh)
+        hd, inner = heads * dp, wx["inner"]
+        kc, vtc, cld = self.kv[n]
+        vt_ld = _rup(HW, 32)
+        A = lambda cols, zero=False: self.alloc(M, cols, zero=zero)
+        xn, t0, qk, a1, t1, q2, a2, t2, hg, y = (A(C_), A(C_), A(2 * hd), A(hd), A(C_), A(hd), A(hd), A(C_), A(inner),
+                                                  A(C_))
+        vt = self.alloc(B, heads, dp, vt_ld, zero=True)
+        cs = float(dh ** -0.5 * 1.4426950408889634)
+        ph = []
+
+        def gemm(a, k1, pw, y_, ldy, n_out, *, ln=0, a2=None, k2=0, lda2=0, res=None, epi=L.XE_PLAIN, lda=None):
+            q = L.XPhase()
+            q.kind, q.n = L.XP_GEMM, HW
+            q.a, q.lda, q.k1 = a.data_ptr(), (lda or a.shape[-1]), k1
+            if a2 is not None:
+                q.a2, q.lda2, q.k2 = a2.data_ptr(), lda2, k2
+            require(k1 + k2 == pw.k, lambda: repr(("xcd K mismatch", k1, k2, pw.k)), ValueError)
+            q.w, q.ntiles, q.n_out = pw.w.data_ptr(), pw.ntiles, n_out
+            if pw.bias is not None:
+                q.bias = pw.bias.data_ptr()
+            if res is not None:
+                q.res, q.ldres = res.data_ptr(), res.shape[-1]
+            q.y, q.ldy, q.epi, q.ln, q.eps = y_.data_ptr(), ldy, epi, ln, 1e-5
+            pair = epi != L.XE_PLAIN
+            grid = xcd_gemm_grid(HW, pw.ntiles, pw.k, pair=pair)
+            if grid is None:
+                return None
+            q.pm, q.pn, q.mb, q.tn = grid
+            ov = os.environ.get("UPGPT_XCD_GRID")  # "pm,pn,mb,tn" forced on every GEMM phase (experiments)
+            if ov:
+                q.pm, q.pn, q.mb, q.tn = (int(v) for v in ov.split(","))
+            return q
+
+        g = L.XPhase()
+        g.kind, g.n, g.a, g.lda, g.k1 = L.XP_GN, HW, x.t.data_ptr(), x.ld, C_
+        g.groups, g.eps, g.silu, g.y, g.ldy = 32, 1e-6, 0, xn.data_ptr(), C_
+        ph.append(g)
+        ph.append(gemm(xn, C_, wx["proj_in"], t0, C_, C_))
+        q = gemm(t0, C_, wx["qkv"], qk, 2 * hd, 2 * hd, ln=1, epi=L.XE_QKV)
+        if q is not None:
+            q.vt, q.vt_ld, q.heads, q.dp, q.vtile0 = vt.data_ptr(), vt_ld, heads, dp, 2 * hd // 16
+        ph.append(q)
+        at = L.XPhase()
+        at.kind, at.n, at.a, at.lda = L.XP_ATTN, HW, qk.data_ptr(), 2 * hd
+        at.kk, at.ldk, at.koff, at.kbs, at.nkv = qk.data_ptr(), 2 * hd, hd, HW * 2 * hd, HW
+        at.vv, at.vt_ld, at.vbs = vt.data_ptr(), vt_ld, heads * dp * vt_ld
+        at.y, at.ldy, at.heads, at.dp, at.scale_log2 = a1.data_ptr(), hd, heads, dp, cs
+        ph.append(at)
+        ph.append(gemm(a1, hd, wx["out1"], t1, C_, C_, res=t0))
+        ph.append(gemm(t1, C_, wx["q2"], q2, hd, hd, ln=1))
+        ax = L.XPhase()
+        ax.kind, ax.n, ax.a, ax.lda = L.XP_ATTN, HW, q2.data_ptr(), hd
+        ax.kk, ax.ldk, ax.koff, ax.kbs, ax.nkv = kc.t.data_ptr(), kc.ld, 0, self.n_ctx * kc.ld, self.n_ctx
+        ax.vv, ax.vt_ld, ax.vbs = vtc.data_ptr(), cld, heads * dp * cld
+        ax.y, ax.ldy, ax.heads, ax.dp, ax.scale_log2 = a2.data_ptr(), hd, heads, dp, cs
+        ph.append(ax)
+        ph.append(gemm(a2, hd, wx["out2"], t2, C_, C_, res=t1))
+        ph.append(gemm(t2, C_, wx["geglu"], hg, inner, inner, ln=1, epi=L.XE_GEGLU))
+        ph.append(gemm(hg, inner, wx["ffout"], y, C_, C_, a2=t2, k2=C_, lda2=C_, res=x.t, lda=inner))
+        if any(q is None for q in ph):
+            return None
+        for q in ph:
+            if self.lib.upk_xcd_phase_check(self.hctx, C.byref(q)) != 0:
+                return None
+        arr = (L.XPhase * len(ph))(*ph)
+        dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
+        self.bufs.append(dev)
+        if getattr(self, "xcd_sync", None) is None:
+            self.xcd_sync = self.alloc(self.lib.upk_xcd_sync_bytes(), dtype=torch.uint8, zero=True)
+        sync = self.xcd_sync
+        fn, h, chk = self.lib.upk_xcd_run_f16, self.hctx, self._chk
+        base, nph, sz = dev.data_ptr(), len(ph), C.sizeof(L.XPhase)
+        if XCD_SPLIT:
+            def run(s):
+                for i in range(nph):
+                    chk(fn(h, base + i * sz, 1, B, sync.data_ptr(), s))
+        else:
+            def run(s):
+                chk(fn(h, base, nph, B, sync.data_ptr(), s))
+        P.add(run, x, wx, kc, vtc, dev, sync, arr, cls="igemm_k1", label="xcd M%d C%d d%d" % (M, C_, dp))
+        fl = 2 * M * sum(wx[k].n * wx[k].k for k in ("proj_in", "out1", "q2", "out2", "geglu", "ffout"))
+        fl += 2 * M * C_ * 3 * heads * dh  # (q | k | v at the real head width)
+        P.igemm_flops += fl
+        P.flops[-1] = fl
+        P.attn_flops += 4 * B * heads * HW * (HW + self.n_ctx) * dh
+        return Act(y, B, x.H, x.W, C_)
+
     def _st(self, P, Lr, x):
         w, v = self.pk.w, self.pk.v
         n = Lr.name
+        out = self.xcd_block(P, Lr, x)
+        if out is not None:
+            return out
         t = n + ".transformer_blocks.0"
         B, HW, M = x.B, x.H * x.W, x.M
         heads, dh = Lr.heads, Lr.dhead
