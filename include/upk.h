@@ -514,9 +514,10 @@ int upk_advance_step(upk_ctx* ctx, int32_t* step, upk_stream stream);
  *  UPK_XP_GEMM  y = epi([a[:, :k1] | a2[:, :k2]] W^T + bias [+ res]).  W packed by upk_xcd_pack_rows order: fp16
  *               [ntiles][K/32][64 lanes][8], lane l = 16 g + i holding W[16 t + i][32 kc + 8 g .. +7] (one MFMA operand
  *               fragment = 1 KiB contiguous; a wave streams its tiles global -> VGPR, no LDS), K = k1 + k2 (k1, k2
- *               multiples of 32).  ln = 1: LayerNorm over a's k1 columns (eps; affine folded into W / bias) applied while
- *               the CU stages its rows in LDS.  The XCD's CUs form a pm x pn grid: mb (<= 64, multiple of 16) rows x
- *               ceil(ntiles / pn) tiles each; tn (1 | 2) tiles per wave pass.  bias fp32 [16 ntiles] in tile order.
+ *               multiples of 32).  ln = 1: LayerNorm over a's k1 columns (eps; affine folded into W / bias): row statistics
+ *               from the staged rows, the normalisation as algebra in the epilogue, rstd (x W'^T - mean colsum) + bias'.  The XCD's CUs form a pm x pn grid: mb (<= 64, multiple of 16) rows x
+ *               ceil(ntiles / pn) tiles each; tn (1 | 2) tiles per wave pass; wk (1 | 2 | 4 | 8; 0 = 1) waves split K of a
+ *               tile group and meet in LDS (then a CU takes at most tn * 8 / wk tiles).  bias fp32 [16 ntiles] in tile order.
  *               epi UPK_XE_PLAIN: y[:, :n_out]; UPK_XE_GEGLU: tiles alternate value / gate (tn = 2), y = v * gelu(g),
  *               n_out = 8 ntiles; UPK_XE_QKV: tiles < vtile0 -> y (q | k), tiles >= vtile0 -> V transposed into
  *               vt [batch, heads, dp, vt_ld].
@@ -550,9 +551,12 @@ typedef struct upk_xphase {
   int32_t ldk, koff, nkv, silu;
   long long kbs, vbs;
   float scale_log2;
-  int32_t pad0;
+  int32_t wk;
   const float* gamma;
   const float* beta;
+  const float* colsum; /* GEMM with ln: fp32 [16 ntiles] column sums of the fp16-rounded weight rows (tile order) */
+  int32_t nx;          /* index of the next GEMM phase of the list (its weights are prefetched during this one), -1 = none */
+  int32_t pad1;
 } upk_xphase;
 /* Bytes of the engine's synchronisation words (arrival / barrier / exit counters per XCD, status): zero them ONCE when
  * allocating; every launch leaves them zeroed again (the last workgroup of an XCD to leave resets its lines). */
@@ -565,6 +569,9 @@ int upk_xcd_run_f16(upk_ctx* ctx, const upk_xphase* phases_dev, int nphases, int
 /* Synchronising check of a finished run: *status_host = 0 ok, 1 a barrier timed out, 2 an XCD did not get exactly 32
  * workgroups (results void in both cases; the words are reset for the next launch). */
 int upk_xcd_status(upk_ctx* ctx, void* sync_ws, int* status_host);
+/* Dev tool (scripts/xcd_timeline.py): while `buf` (device, 256 * nphases * 8 int64) is set, thread 0 of every workgroup
+ * stamps the shader clock per phase: start, A tile staged (GEMM phases), body done, behind the barrier.  NULL = off. */
+void upk_xcd_dev_timeline(void* buf);
 
 /* ------------------------------------------------------------------ */
 /* HIP graph helpers (the 50-step loop replays one captured step).      */

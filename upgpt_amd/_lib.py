@@ -28,7 +28,7 @@ SYMBOLS = [
     "upk_patchify_nchw_f32_f16", "upk_vit_assemble_f16", "upk_gather_rows_f16",
     "upk_advance_step", "upk_step_autoadvance", "upk_kernel_launches", "upk_graph_begin", "upk_graph_end", "upk_graph_launch", "upk_graph_destroy",
     "upk_prof_enable", "upk_prof_collect",
-    "upk_xcd_sync_bytes", "upk_xcd_phase_check", "upk_xcd_run_f16", "upk_xcd_status",
+    "upk_xcd_sync_bytes", "upk_xcd_phase_check", "upk_xcd_run_f16", "upk_xcd_status", "upk_xcd_dev_timeline",
 ]
 
 F_SILU, F_GEGLU, F_OUT_F32, F_OUT_NCHW_F32, F_UPSAMPLE2X, F_PAD_ASYM = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
@@ -124,8 +124,9 @@ class XPhase(C.Structure):
         ("kk", C.c_void_p), ("vv", C.c_void_p),
         ("ldk", C.c_int32), ("koff", C.c_int32), ("nkv", C.c_int32), ("silu", C.c_int32),
         ("kbs", C.c_longlong), ("vbs", C.c_longlong),
-        ("scale_log2", C.c_float), ("pad0", C.c_int32),
+        ("scale_log2", C.c_float), ("wk", C.c_int32),
         ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("colsum", C.c_void_p), ("nx", C.c_int32), ("pad1", C.c_int32),
     ]
 
 
@@ -209,6 +210,7 @@ def load_library(path=None):
             "upk_xcd_phase_check": (C.c_int, [vp, C.POINTER(XPhase)]),
             "upk_xcd_run_f16": (C.c_int, [vp, vp, i32, i32, vp, vp]),
             "upk_xcd_status": (C.c_int, [vp, vp, C.POINTER(C.c_int)]),
+            "upk_xcd_dev_timeline": (None, [vp]),
         }
         require(sorted(protos) == sorted(SYMBOLS), "ctypes prototypes and SYMBOLS differ", RuntimeError)
         for name, (res, args) in protos.items():

@@ -115,9 +115,12 @@ XB_ROWS = int(os.environ.get("UPGPT_XB_ROWS", "0"))  # rows per workgroup (16 / 
 HBLOCK = os.environ.get("UPGPT_HBLOCK", "auto")
 HBLOCK_GN = os.environ.get("UPGPT_HBLOCK_GN", "1") == "1"  # SpatialTransformer.norm applied on the tile inside that launch
 # per-XCD persistent engine (csrc/xcd.hip, include/upk.h upk_xcd_run_f16): a whole SpatialTransformer as ONE launch, sample b
-# on XCD b % 8.  "auto" = batches that are a multiple of 8 at feature maps of <= XCD_MAXN pixels, "1" wherever the engine
-# takes the shape (any batch: tests), "0" off.  UPGPT_XCD_SPLIT=1: one launch per phase (debugging aid).
-XCD = os.environ.get("UPGPT_XCD", "auto")
+# on XCD b % 8, XCD-local barriers (1.04 us measured) between its ten phases.  Built, parity-green and measured in round 5
+# (DESIGN.md 12): inside the replayed forward a block costs 130 us on the engine against 95 us as a launch chain — every
+# phase re-stages its rows through the XCD's shared L2 and pays 2-3 L2 / HBM round trips of 1-2.5 us that a barrier cannot
+# hide — so it is OFF by default: "0" off, "1" wherever the engine takes the shape (any batch: the GPU tests), "auto" =
+# batches that are a multiple of 8 at feature maps of <= XCD_MAXN pixels.  UPGPT_XCD_SPLIT=1: one launch per phase.
+XCD = os.environ.get("UPGPT_XCD", "0")
 XCD_MAXN = int(os.environ.get("UPGPT_XCD_MAXN", "256"))
 XCD_SPLIT = os.environ.get("UPGPT_XCD_SPLIT", "0") == "1"
 LN_LAUNCH_US = 5.0  # what a separate LayerNorm launch costs inside the replayed forward (3.8 us of kernel + its boundary: DESIGN.md 11i / 11j)
@@ -155,7 +158,7 @@ class PW:
 
 class PWX:
     """A weight packed for the per-XCD engine (Packer.pack_xcd)."""
-    __slots__ = ("w", "bias", "ntiles", "k", "n")
+    __slots__ = ("w", "bias", "ntiles", "k", "n", "colsum")
 
 
 class Packer:
@@ -297,6 +300,7 @@ class Packer:
             px.bias = w.new_zeros(N16)
             px.bias[:N] = bias.float().to(self.dev)
         px.ntiles, px.k, px.n = T, K32, N
+        px.colsum = wp.half().float().sum(dim=1).contiguous()  # (of the fp16-rounded rows: folded-LayerNorm GEMMs)
         return px
 
 
@@ -1050,35 +1054,49 @@ def _pack_xcd_block(self, pk, get, n, t, Lr, heads, dh, dp):
 PackedUNet._pack_xcd_block = _pack_xcd_block
 
 
-def xcd_gemm_grid(n, ntiles, K, pair=False, lds_bytes=152 * 1024 - 64):
-    """(pm, pn, mb, tn) of a per-XCD engine GEMM: the XCD's 32 CUs as a pm x pn grid of (mb rows) x (ntiles / pn column
-    tiles), tn tiles per wave pass.  Cost model in CU cycles: staging of the CU's rows (L2 -> registers -> LDS) +
-    max(weight stream into the CU at ~40 B / clk, MFMA issue at 4 SIMDs x one 16x16x32 per 17 clk, LDS fragment reads at
-    256 B / clk), the serial chain of the busiest wave on top.  pair: tiles come in (value, gate) / q|k|v pairs."""
+def xcd_gemm_grid(n, ntiles, K, pair=False, ln=False, lds_bytes=152 * 1024 - 64):
+    """(pm, pn, mb, tn, wk) of a per-XCD engine GEMM: the XCD's 32 CUs as a pm x pn grid of (mb rows) x (ntiles / pn column
+    tiles); inside a CU the 8 waves as (8 / wk) tile groups of tn tiles x wk slices of K.  Cost model in CU cycles, from
+    the engine's in-kernel stamps (scripts/xcd_timeline.py): staging of the CU's rows (one L2 round trip + the bytes at
+    ~64 B / clk) + max(weight stream into the CU at ~45 B / clk, MFMA issue at 4 SIMDs x one 16x16x32 per 17 clk, the serial
+    chain of the busiest wave: >= 100 clk per chunk with 8 fragments in flight at an L2 latency of ~800 clk) + the LDS
+    reduction when K is split.  pair: tiles come in (value, gate) / q|k|v pairs."""
     KC = (K + 31) // 32
-    Kpad = _rup(K, 128)
     best = None
     for pm in (1, 2, 4, 8, 16, 32):
         mb = _rup((n + pm - 1) // pm, 16)
-        if mb > 64 or mb * (Kpad * 2 + 32) > lds_bytes:
+        if mb > 64:
             continue
         pm_eff = (n + mb - 1) // mb
-        pn = max(1, min(32 // pm_eff, ntiles // 2 if pair else ntiles))
-        tpc = (ntiles + pn - 1) // pn
-        if pair and tpc % 2:
-            tpc += 1
         tm = mb // 16
-        for tn in ((2,) if pair else (1, 2)):
-            units = (tpc + tn - 1) // tn
-            rounds = (units + 7) // 8
-            stage = mb * Kpad * 2 / 30.0
-            fill = tpc * 16 * K * 2 / 40.0
-            mfma = tm * tpc * KC * 17 / 4.0
-            ldsr = tm * units * KC * 4.0
-            chain = rounds * KC * (tm * tn * 17 + 40)
-            cost = stage + max(fill, mfma, ldsr, chain)
-            if best is None or cost < best[0]:
-                best = (cost, pm_eff, pn, mb, tn)
+        for pn0 in range(1, 32 // pm_eff + 1):
+            pn = min(pn0, ntiles // 2 if pair else ntiles)
+            tpc = (ntiles + pn - 1) // pn
+            if pair and tpc % 2:
+                tpc += 1
+            pn = (ntiles + tpc - 1) // tpc
+            for tn in ((2,) if pair else (1, 2)):
+                units = (tpc + tn - 1) // tn
+                for wk in (1, 2, 4, 8):
+                    wn = 8 // wk
+                    if wk > 1 and units > wn:
+                        continue
+                    kc_per = _rup((KC + wk - 1) // wk, 4)
+                    Kpad = kc_per * wk * 32
+                    if mb * (Kpad * 2 + 96) > lds_bytes:
+                        continue
+                    rounds = (units + wn - 1) // wn
+                    active = min(8, units * wk)
+                    # (measured: the A tile arrives from the shared L2 at ~25 B / clk per CU with all 32 CUs pulling,
+                    # a ring fill of 16 KiB of L2-resident weights takes ~1.5 k clk, LayerNorm staging ~1 clk per 50 elements)
+                    stage = 1500 + mb * Kpad * 2 / 25.0 + ((1500 + mb * Kpad / 50.0) if ln else 0.0)
+                    fill = tpc * 16 * K * 2 / 40.0
+                    mfma = tm * tpc * KC * 17 / 4.0
+                    per_chunk = max(1500.0 * tn / 16.0, tm * tn * 17.0 * (2 if active > 4 else 1))
+                    chain = rounds * kc_per * per_chunk + 1500
+                    cost = stage + max(fill, mfma, chain) + (800 if wk > 1 else 0)
+                    if best is None or cost < best[0]:
+                        best = (cost, pm_eff, pn, mb, tn, wk)
     return None if best is None else best[1:]
 
 
@@ -1212,14 +1230,16 @@ class UNetPlan(Emitter):
             if res is not None:
                 q.res, q.ldres = res.data_ptr(), res.shape[-1]
             q.y, q.ldy, q.epi, q.ln, q.eps = y_.data_ptr(), ldy, epi, ln, 1e-5
+            if ln:
+                q.colsum = pw.colsum.data_ptr()
             pair = epi != L.XE_PLAIN
-            grid = xcd_gemm_grid(HW, pw.ntiles, pw.k, pair=pair)
+            grid = xcd_gemm_grid(HW, pw.ntiles, pw.k, pair=pair, ln=bool(ln))
             if grid is None:
                 return None
-            q.pm, q.pn, q.mb, q.tn = grid
-            ov = os.environ.get("UPGPT_XCD_GRID")  # "pm,pn,mb,tn" forced on every GEMM phase (experiments)
+            q.pm, q.pn, q.mb, q.tn, q.wk = grid
+            ov = os.environ.get("UPGPT_XCD_GRID")  # "pm,pn,mb,tn,wk" forced on every GEMM phase (experiments)
             if ov:
-                q.pm, q.pn, q.mb, q.tn = (int(v) for v in ov.split(","))
+                q.pm, q.pn, q.mb, q.tn, q.wk = (int(v) for v in ov.split(","))
             return q
 
         g = L.XPhase()
@@ -1248,11 +1268,18 @@ class UNetPlan(Emitter):
         ph.append(gemm(a2, hd, wx["out2"], t2, C_, C_, res=t1))
         ph.append(gemm(t2, C_, wx["geglu"], hg, inner, inner, ln=1, epi=L.XE_GEGLU))
         ph.append(gemm(hg, inner, wx["ffout"], y, C_, C_, a2=t2, k2=C_, lda2=C_, res=x.t, lda=inner))
+        verbose = os.environ.get("UPGPT_XCD_VERBOSE", "0") == "1"
         if any(q is None for q in ph):
+            if verbose:
+                print("[xcd] %s: no CU grid for phase %d" % (n, [q is None for q in ph].index(True)))
             return None
-        for q in ph:
+        for i, q in enumerate(ph):
             if self.lib.upk_xcd_phase_check(self.hctx, C.byref(q)) != 0:
+                if verbose:
+                    print("[xcd] %s: phase %d refused: %s" % (n, i, (self.lib.upk_last_error(self.hctx) or b"").decode()))
                 return None
+        for i, q in enumerate(ph):  # the next GEMM phase: its weights are prefetched while phase i runs
+            q.nx = next((k for k in range(i + 1, len(ph)) if ph[k].kind == L.XP_GEMM), -1)
         arr = (L.XPhase * len(ph))(*ph)
         dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev)
         self.bufs.append(dev)
@@ -1268,6 +1295,9 @@ class UNetPlan(Emitter):
         else:
             def run(s):
                 chk(fn(h, base, nph, B, sync.data_ptr(), s))
+        if os.environ.get("UPGPT_XCD_KEEP", "0") == "1":  # (scripts/xcd_debug.py compares every intermediate)
+            self.__dict__.setdefault("xcd_dbg", {})[n] = dict(x=x.t, xn=xn, t0=t0, qk=qk, vt=vt, a1=a1, t1=t1, q2=q2, a2=a2,
+                                                              t2=t2, hg=hg, y=y, kc=kc.t, vtc=vtc)
         P.add(run, x, wx, kc, vtc, dev, sync, arr, cls="igemm_k1", label="xcd M%d C%d d%d" % (M, C_, dp))
         fl = 2 * M * sum(wx[k].n * wx[k].k for k in ("proj_in", "out1", "q2", "out2", "geglu", "ffout"))
         fl += 2 * M * C_ * 3 * heads * dh  # (q | k | v at the real head width)
