@@ -227,13 +227,28 @@ def dominant_kernel_roofline(model, wl, reps=20, ncand=8):
     with model.ema_scope():
         plan = unet.plan(wl.B, wl.hw[0], wl.hw[1], 87, wl.S, "sampler")
         body, ctx = plan.body, plan.ctx
+        # group by what rocprofv3 reports as one row: kernel instantiation (= the tuned tile configuration + loader / epilogue
+        # variant a launch descriptor selects) x grid (rows, output columns, split-K) — NOT by shape label: the launches of
+        # one instantiation on one grid (e.g. the 3x3 224 -> 224 conv of level 0 with a timestep row, with a residual, with an
+        # appended skip segment of 448 or 672 channels) are one kernel to the profiler and to the hardware
+        def kernel_key(i):
+            d, lab = body.meta[i], body.labels[i]
+            if d is None or not d.tune_cfg:
+                return lab  # (row-chain / attention launches, untuned convs: the label is the kernel + grid)
+            name = ctx.lib.upk_conv_config_name(d.tune_cfg - 1).decode()
+            app = "+app" if (d.c3 or d.c4) else ""
+            lnf = "+lnf" if d.ln_colsum and not d.ln_rows_in else ""
+            M = d.batch * ((d.in_h * (2 if d.flags & 0x10 else 1) + d.stride - 1) // d.stride) * (
+                (d.in_w * (2 if d.flags & 0x10 else 1) + d.stride - 1) // d.stride)
+            return "%s%s%s k%d M%d N%d z%d" % (name, app, lnf, d.ksize, M, d.n_pad, max(1, d.tune_splitk))
+
         groups = {}
         for i, (f, c, lab) in enumerate(zip(body.flops, body.cls, body.labels)):
             if c.startswith("igemm") or c == "attention":
-                groups.setdefault(lab, []).append(i)
+                groups.setdefault(kernel_key(i), []).append(i)
         exe = lambda f, lab: f * 4.0 / 9.0 if lab.endswith("_ph") else float(f)
         # candidates: the groups a static estimate (launches x (6 us + FLOPs at 0.4 PFLOP/s)) ranks highest
-        est = lambda lab, idx: sum(6e-6 + exe(body.flops[i], lab) / 0.4e15 for i in idx)
+        est = lambda key, idx: sum(6e-6 + exe(body.flops[i], body.labels[i]) / 0.4e15 for i in idx)
         cands = sorted(groups.items(), key=lambda kv: -est(*kv))[:ncand]
         s = torch.cuda.Stream(device=plan.dev)
 
@@ -268,10 +283,11 @@ def dominant_kernel_roofline(model, wl, reps=20, ncand=8):
         plan.prep.run()  # the ablated replays left garbage in the activations
         torch.cuda.synchronize()
     ms, lab, idx, full = best
-    fl = sum(exe(body.flops[i], lab) for i in idx)
-    out = {"label": lab, "launches_per_fwd": len(idx), "ms_per_fwd_in_situ": ms, "share_of_forward": ms / full,
+    fl = sum(exe(body.flops[i], body.labels[i]) for i in idx)
+    out = {"label": lab, "shapes": sorted(set(body.labels[i] for i in idx)), "launches_per_fwd": len(idx), "ms_per_fwd_in_situ": ms, "share_of_forward": ms / full,
            "us_per_launch_in_situ": ms * 1e3 / len(idx), "method": "graph-replay difference with / without the group, "
-           "median of 3 pairs; candidates: the %d label groups a static estimate ranks highest" % len(cands)}
+           "median of 3 pairs; groups = (kernel instantiation, grid) as rocprofv3 rows; candidates: the %d groups a "
+           "static estimate ranks highest" % len(cands)}
     if fl:
         tf = fl / (ms * 1e-3) / 1e12
         out.update({"flops_per_fwd": fl, "achieved": tf, "frac": tf / PEAK_MFMA_F16_TFLOPS})

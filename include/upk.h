@@ -409,7 +409,11 @@ int upk_vit_assemble_f16(upk_ctx* ctx, const void* patch_emb, int ld_patch, cons
  * and model.py:38-39, eps 1e-6) and the following SiLU/swish (openaimodel.py:203,227).
  * stats_ws: fp32 scratch, >= upk_groupnorm_ws_bytes(batch, hw) bytes (its contents after the call are unspecified:
  * feature maps of <= 64 pixels are normalised by ONE launch that keeps a (sample, group) in registers and never
- * touches it; larger ones by a statistics pass that fills it and an apply pass that reads it). */
+ * touches it; larger ones by a statistics pass that fills it and an apply pass that reads it).
+ * Reproducibility: every path sums in a fixed order (reruns are bit-identical).  ACROSS paths — this call, the apply pass
+ * on a producer's partial statistics (upk_groupnorm_apply_nhwc_f16), a normalising split-K reduce (gno_*) — results are
+ * bit-identical for feature maps of > 64 pixels only; at <= 64 pixels the one-launch kernel sums in another order and
+ * agrees to fp16 rounding (so a tensor may normalise to different bits under different tuning files, never within one). */
 int upk_groupnorm_nhwc_f16(upk_ctx* ctx, const void* x1, int c1, int ld1, const void* x2, int c2,
                            int ld2, int batch, int hw, int groups, const float* gamma,
                            const float* beta, float eps, int fuse_silu, void* y, int ldy,

@@ -125,6 +125,48 @@ def test_conv_all_configs_and_splitk(ctx):
     assert ran >= 3 * 62
 
 
+def test_splitk_partials_that_cancel_and_exceed_fp16(ctx):
+    """split-K partials leave as fp16 (igemm_common.h slab_store).  (a) Partials ~2000x the output that
+    cancel across the K slices: the fp32 sum of the rounded slices keeps the output to the partials' 2^-11, i.e. the
+    error is bounded by max|partial| 2^-10, not by inf / nan.  (b) Partials beyond 65504: the store saturates, the result
+    stays finite (an fp32-slab build would be exact; the UNet / VAE never come near either regime)."""
+    B, H, W, cin, cout = 1, 8, 8, 256, 64
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(B, cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin)).to(DEV)
+    # first half of K: +big, second half: -big  ->  each split-K slice holds a partial of magnitude ~big * sqrt(cin / 2)
+    big = 200.0
+    x2 = x.clone()
+    x2[:, : cin // 2] += big
+    w2 = w.clone()
+    w2[:, cin // 2:, 0, 0] = w[:, : cin // 2, 0, 0]  # same weights on both halves ...
+    x2[:, cin // 2:] = x[:, cin // 2:] - (x2[:, : cin // 2] - x[:, : cin // 2])  # ... and the big term with opposite sign
+    ref = conv_ref(x2, w2, None)
+    part = F.conv2d(x2[:, : cin // 2].half().float(), w2[:, : cin // 2].half().float())
+    assert float(part.abs().max()) > 50 * float(ref.abs().max())  # (the slices really are much larger than their sum)
+    y = torch.zeros(B, H, W, cout, device=DEV, dtype=torch.float16)
+    try:
+        ctx.conv_override(-1, 2)
+        ctx.conv(make_desc(ctx, nhwc16(x2), w2, None, y))
+        torch.cuda.synchronize()
+    finally:
+        ctx.conv_override(-1, 0)
+    err = float((y.permute(0, 3, 1, 2).float() - ref).abs().max())
+    assert torch.isfinite(y).all() and err <= float(part.abs().max()) * 2.0 ** -9, (err, float(part.abs().max()))
+    # (b) beyond the fp16 range
+    x3 = x2.clone()
+    x3[:, : cin // 2] *= 400.0
+    x3[:, cin // 2:] *= 400.0
+    y3 = torch.zeros(B, H, W, cout, device=DEV, dtype=torch.float16)
+    try:
+        ctx.conv_override(-1, 2)
+        ctx.conv(make_desc(ctx, nhwc16(x3.clamp(-60000, 60000)), w2, None, y3))
+        torch.cuda.synchronize()
+    finally:
+        ctx.conv_override(-1, 0)
+    assert not torch.isnan(y3).any(), "saturated partials must not turn into nan"
+
+
 @pytest.mark.parametrize("ks,c,c3,c4,cout,hw", [(3, 64, 96, 32, 224, (12, 10)), (3, 96, 64, 0, 64, (8, 8)),
                                                (1, 64, 32, 64, 96, (9, 7)), (3, 224, 448, 224, 224, (6, 4))])
 def test_conv_with_appended_1x1_segment(ctx, ks, c, c3, c4, cout, hw):

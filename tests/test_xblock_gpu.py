@@ -247,3 +247,49 @@ def test_unet_forward_with_and_without_the_fused_head():
     e0, n0 = run("0")
     assert n0 == 0 and n1 == 5, (n0, n1)
     assert float(((e1 - e0) ** 2).mean()) < 1e-5 * max(1.0, float((e0 ** 2).mean()))
+
+
+def test_head_block_behind_a_split_k_producer_takes_the_reduce_pass_groupnorm():
+    """when the conv in front of a fused SpatialTransformer head splits K, the GroupNorm is applied by the
+    producer's reduce pass (include/upk.h gno_*, mode 3 of upk_conv_gn_fused) and the head runs WITHOUT its in-kernel
+    GroupNorm.  The tuning table decides whether that path is taken, so this test forces it: every producer of a head's
+    input is pinned to split-K = 2, and the forward must agree with the separate-GroupNorm path (HBLOCK_GN off)."""
+    import ctypes as C
+    import upgpt_amd
+    from upgpt_amd import engine, synth
+    m = upgpt_amd.build_model("bbox")
+    synth.fill_module_(m)
+    m = m.cuda()
+    inp = synth.synth_inputs(8, (32, 32), 4, 87, 768, seed=3, text_only=True)
+    cond = {"c_crossattn": inp["c_crossattn"].cuda(), "c_concat": [inp["c_concat"].cuda()]}
+    t = torch.full((8,), 601, dtype=torch.long, device=DEV)
+    unet = m.model.diffusion_model
+
+    def run(gn_fold, force_split):
+        old = engine.HBLOCK_GN
+        engine.HBLOCK_GN = gn_fold
+        try:
+            for pl in unet._plans.values():
+                pl.close()
+            unet._plans.clear()
+            pl = unet.plan(8, 32, 32, 87, 8, "forward")
+            heads = [i for i, lab in enumerate(pl.body.labels) if lab.startswith("hblock ")]
+            assert len(heads) == 5
+            forced = 0
+            if force_split:
+                for i in heads:
+                    j = max(k for k in range(i) if pl.body.meta[k] is not None)  # the conv that wrote the head's input
+                    d = pl.body.meta[j]
+                    d.tune_splitk = 2
+                    mode, nblk = C.c_int(0), C.c_int(0)
+                    pl.ctx._chk(pl.lib.upk_conv_gn_fused(pl.hctx, C.byref(d), C.byref(mode), C.byref(nblk)))
+                    forced += mode.value == 3
+            eps = m.apply_model(inp["x_T"].cuda(), t, cond)
+            return eps.float().cpu(), forced
+        finally:
+            engine.HBLOCK_GN = old
+
+    e_ref, _ = run(False, False)
+    e_m3, forced = run(True, True)
+    assert forced >= 1, "no producer took the normalising reduce pass: the forced split-K did not arm mode 3"
+    assert float(((e_m3 - e_ref) ** 2).mean()) < 1e-5 * max(1.0, float((e_ref ** 2).mean()))

@@ -14,7 +14,8 @@
 //     [rows][32 fp16] with a 16-byte-chunk XOR swizzle that makes ds_read_b128 of the
 //     MFMA fragments conflict free (see lds_swz()).
 //   * weights are pre-packed [K/32][n_pad][32] so a B tile is ONE contiguous run.
-//   * split-K over blockIdx.z with fp32 partial slabs in caller workspace and a
+//   * split-K over blockIdx.z with partial slabs in caller workspace (fp32 accumulation inside a slice, the partial
+//     rounded to fp16 — saturating — on its way out, summed in fp32 in slice order) and a
 //     deterministic reduce+epilogue kernel (deep UNet levels have M = 96..384 rows only).
 //
 // Replaces F.conv2d / F.linear at the call sites listed in include/upk.h.

@@ -17,7 +17,7 @@ enum {
   ABL_NOSTORE = 0x400000,   // plain epilogue: everything but the global stores of the output
   ABL_NOGNP = 0x800000,     // plain epilogue: no GroupNorm channel partials (column sums, LDS exchange, their stores)
   ABL_NOEPILD = 0x1000000,  // plain epilogue: operands (bias, row vector, residual) read as zeros, no loads
-  ABL_NOSLAB = 0x2000000,   // split-K launches: the fp32 partial slabs are not written
+  ABL_NOSLAB = 0x2000000,   // split-K launches: the partial slabs (fp16, fp32 with -DUPK_SLAB_F32) are not written
 };
 // The ablation / timeline hooks are compiled in only for dev builds (UPK_CXXFLAGS=-DUPK_DEV, scripts/ablate.sh,
 // scripts/timeline*.py): even as never-taken runtime tests they cost scalar registers and instructions in the loops.
@@ -45,7 +45,7 @@ struct IgemmArgs {
   int ldy;
   f16* vt;
   int vt_from, vt_heads, vt_dhead, vt_ld, vt_tokens;
-  float* partial;  // split-K slabs [splitk][M][npad] fp32, or nullptr
+  float* partial;  // split-K slabs [splitk][M][npad] of slab_t (fp16 unless -DUPK_SLAB_F32; typed float* for the ABI's workspace), or nullptr
   int M, n_out;
   int B, HS, WS;   // stored input dims
   int HL, WL;      // logical input dims (after optional 2x upsample)
@@ -110,7 +110,10 @@ __device__ __forceinline__ void slab_store(slab_t* p, f32x4 v) {
 #ifdef UPK_SLAB_F32
   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 #else
-  const f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+  // saturating: a partial beyond the fp16 range (K slices of large, cancelling activations) stays finite, so the fp32 sum
+  // of the slices is off by the clipped amount instead of inf / nan (v_med3_f32: one VALU instruction per element)
+  const f16x4 h = {(f16)__builtin_amdgcn_fmed3f(v[0], -65504.f, 65504.f), (f16)__builtin_amdgcn_fmed3f(v[1], -65504.f, 65504.f),
+                   (f16)__builtin_amdgcn_fmed3f(v[2], -65504.f, 65504.f), (f16)__builtin_amdgcn_fmed3f(v[3], -65504.f, 65504.f)};
   asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(h) : "memory");
 #endif
 }

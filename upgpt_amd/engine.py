@@ -66,14 +66,21 @@ class TuneCache:
             idx = {nm: i for i, nm in enumerate(cur)}
             remap = {i: idx.get(nm, -1) for i, nm in enumerate(self.names)}
             for k in list(self.d):
-                c = remap.get(int(self.d[k][0]), -1)
+                try:
+                    c = remap.get(int(self.d[k][0]), -1)
+                except (TypeError, ValueError, IndexError, KeyError):
+                    c = -1  # (a malformed entry is dropped, never a reason to fail)
                 if c < 0:
                     del self.d[k]
                 else:
                     self.d[k][0] = c
         else:
             for k in list(self.d):
-                if not 0 <= int(self.d[k][0]) < n:
+                try:
+                    ok = 0 <= int(self.d[k][0]) < n
+                except (TypeError, ValueError, IndexError, KeyError):
+                    ok = False
+                if not ok:
                     del self.d[k]
         self.names = cur
 
@@ -81,6 +88,8 @@ class TuneCache:
         return self.d.get(key)
 
     def put(self, key, cfg, sk, best_us, dflt_us):
+        # indices written now refer to THIS library's configuration list: the stored ones must have been re-indexed first
+        require(self._bound, "TuneCache.put before bind(lib): stored and new configuration indices would mix", RuntimeError)
         self.d[key] = [int(cfg), int(sk), round(float(best_us), 2), round(float(dflt_us), 2)]
         self.dirty = True
         return self.d[key]
@@ -347,6 +356,7 @@ class Program:
         self.labels = []
         self.keep = []
         self.flops = []  # algorithmic FLOPs of each op (conv / GEMM launches; 0 elsewhere)
+        self.meta = []   # ConvDesc of a upk_conv2d launch (its tuned configuration names the kernel instantiation), else None
         self.igemm_flops = 0
         self.attn_flops = 0
         self.n_launch = 0
@@ -365,6 +375,7 @@ class Program:
     def add(self, fn, *keep, cls="other", label=None):
         self.ops.append(fn)
         self.flops.append(0)
+        self.meta.append(None)
         self.cls.append(cls)
         self.labels.append(label or cls)
         self.keep.extend(keep)
@@ -643,6 +654,7 @@ class Emitter:
             P.add(lambda s: chk(fn(h, ref, s)), *keep, cls="igemm_k%d" % ks, label=key)
         P.igemm_flops += 2 * M * pw.n_real * pw.k_real
         P.flops[-1] = 2 * M * pw.n_real * pw.k_real
+        P.meta[-1] = d
         return ret
 
     class GnProvider:
@@ -1695,7 +1707,9 @@ class SamplerState:
         graph serves every position of the loop; the guidance scale is a kernel argument, so each scale value gets its
         own graph).  nsteps > 1 saves the graph-to-graph launch gap of the steps inside."""
         key = (with_noise, float(scale) if self.cfg else 1.0) + ((int(nsteps),) if nsteps != 1 else ())
-        g = self.graphs.get(key)
+        g = self.graphs.pop(key, None)
+        if g is not None:
+            self.graphs[key] = g  # (most recently used last: eviction takes the least recently used graph)
         if g is None:
             p = self.plan
             if with_noise:
@@ -1713,7 +1727,9 @@ class SamplerState:
                 rc = p.lib.upk_graph_end(p.hctx, sp, C.byref(gh))
             p.ctx._chk(rc)
             torch.cuda.current_stream(p.dev).wait_stream(side)
-            if len(self.graphs) >= 8:  # guidance scales seen so far: bound the number of instantiated graphs
+            # one sample() makes up to three graphs per (noise, scale) (full groups of steps, the remainder, single steps
+            # around a callback): 16 graphs = five guidance scales in rotation; least recently used first
+            if len(self.graphs) >= 16:
                 torch.cuda.synchronize(p.dev)  # (the evicted graph may still be executing)
                 p.ctx.graph_destroy(self.graphs.pop(next(iter(self.graphs))))
             g = self.graphs[key] = gh
