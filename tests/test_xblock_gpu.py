@@ -249,11 +249,13 @@ def test_unet_forward_with_and_without_the_fused_head():
     assert float(((e1 - e0) ** 2).mean()) < 1e-5 * max(1.0, float((e0 ** 2).mean()))
 
 
-def test_head_block_behind_a_split_k_producer_takes_the_reduce_pass_groupnorm():
-    """when the conv in front of a fused SpatialTransformer head splits K, the GroupNorm is applied by the
-    producer's reduce pass (include/upk.h gno_*, mode 3 of upk_conv_gn_fused) and the head runs WITHOUT its in-kernel
-    GroupNorm.  The tuning table decides whether that path is taken, so this test forces it: every producer of a head's
-    input is pinned to split-K = 2, and the forward must agree with the separate-GroupNorm path (HBLOCK_GN off)."""
+def test_head_block_behind_a_split_k_producer():
+    """which GroupNorm path a fused SpatialTransformer head takes is decided by the TUNED configuration of
+    the conv in front of it (upk_conv_gn_fused: 2 = channel partials of an unsplit launch -> normalisation inside the head;
+    1 = group partials of a split-K reduce -> apply launch + plain head; 3 = the reduce pass normalises itself, reachable
+    at the 32x32 level only with the dev knob UPK_GNAPPLY_NVMAX raised).  A tuning change could flip the path silently, so
+    this test forces the other one: every producer of a head's input is pinned to split-K = 2, and the forward must agree
+    with the separate-GroupNorm reference path (HBLOCK_GN off)."""
     import ctypes as C
     import upgpt_amd
     from upgpt_amd import engine, synth
@@ -283,7 +285,7 @@ def test_head_block_behind_a_split_k_producer_takes_the_reduce_pass_groupnorm():
                     d.tune_splitk = 2
                     mode, nblk = C.c_int(0), C.c_int(0)
                     pl.ctx._chk(pl.lib.upk_conv_gn_fused(pl.hctx, C.byref(d), C.byref(mode), C.byref(nblk)))
-                    forced += mode.value == 3
+                    forced += mode.value in (1, 3)
             eps = m.apply_model(inp["x_T"].cuda(), t, cond)
             return eps.float().cpu(), forced
         finally:
@@ -291,5 +293,5 @@ def test_head_block_behind_a_split_k_producer_takes_the_reduce_pass_groupnorm():
 
     e_ref, _ = run(False, False)
     e_m3, forced = run(True, True)
-    assert forced >= 1, "no producer took the normalising reduce pass: the forced split-K did not arm mode 3"
+    assert forced == 5, "the forced split-K did not move the heads' producers off the channel-partials path"
     assert float(((e_m3 - e_ref) ** 2).mean()) < 1e-5 * max(1.0, float((e_ref ** 2).mean()))
