@@ -216,8 +216,8 @@ def top_kernel_roofline(model, wl, reps=40):
 
 
 def dominant_kernel_roofline(model, wl, reps=20, ncand=8):
-    """The (kernel, shape) with the largest share of the forward's GPU time, timed IN SITU: the launches of the forward
-    are grouped by label (= shape signature: launches of one group run the same kernel on the same grid), and for the
+    """The (kernel, grid) with the largest share of the forward's GPU time, timed IN SITU: the launches of the forward
+    are grouped by kernel instantiation x grid (what rocprofv3 reports as one row), and for the
     `ncand` groups with the most FLOPs x launches the captured forward is replayed with and without the group (HIP
     events on the launch stream, median of 3 back-to-back pairs); the group with the largest difference is reported
     with its per-launch time inside the forward — cold weights, freshly produced activations, its split-K reduce and
@@ -294,7 +294,8 @@ def dominant_kernel_roofline(model, wl, reps=20, ncand=8):
     return out
 
 
-TRAFFIC_FILE = "profiles/r04_igemm_traffic.json"
+TRAFFIC_FILE = "profiles/r05_igemm_traffic.json"
+PEAK_L2_TBS = 34.5  # aggregate of the eight XCD L2s, /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def igemm_traffic_bytes_per_launch():
@@ -315,10 +316,10 @@ def igemm_traffic_bytes_per_launch():
             built = None
         if d.get("kernel_sources_sha256") != built:
             return None, "STALE, not reported: %s was collected for kernel sources %s, this build is %s" % (
-                src, str(d.get("kernel_sources_sha256"))[:12], str(built)[:12])
-        return d["bytes_per_launch"], src
+                src, str(d.get("kernel_sources_sha256"))[:12], str(built)[:12]), None
+        return d["bytes_per_launch"], src, d.get("dominant_kernel_l2")
     except Exception:
-        return None, None
+        return None, None, None
 
 
 def unet_forward_ms(model, wl, reps=20):
@@ -533,7 +534,7 @@ def main():
         prof, ig_flops, at_flops, n_kernels, body_ms = kernel_class_profile(model, wl)
         ig_ms = prof["igemm"]["ms_per_fwd"]
         achieved = ig_flops / (ig_ms * 1e-3) / 1e12
-        traffic, traffic_src = igemm_traffic_bytes_per_launch()
+        traffic, traffic_src, dom_l2 = igemm_traffic_bytes_per_launch()
         t_model, f_model, b_model = arch.unet_layer_roofline(a, args.batch, hw[0], hw[1], 87, PEAK_MFMA_F16_TFLOPS * 1e12,
                                                              PEAK_HBM_TBS * 1e12)
         n_api, n_k = prof["igemm"]["launches_per_fwd"], prof["igemm"]["kernels_per_fwd"]
@@ -552,12 +553,22 @@ def main():
             "dominant_kernel": dominant_kernel_roofline(model, wl),
             "achieved": achieved, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F16_TFLOPS,
             "traffic": traffic, "traffic_source": traffic_src,
+            # the bound the attribution of round 4 established for the dominant conv is the per-CU L2 -> LDS fill, not the
+            # fabric: its L2 request bytes per launch (PMC, committed summary) and the share of the aggregate L2 bandwidth
+            # they take over the launch's in-situ duration
+            "l2_bytes_per_launch": None, "l2_frac": None,
             "algorithmic_flops_per_fwd": ig_flops, "launches_per_fwd": n_api, "kernels_per_fwd": n_k,
             "avg_launch_us": ig_ms * 1e3 / max(1, n_api), "avg_kernel_us": ig_ms * 1e3 / max(1, n_k),
             # the honest ceiling of the WHOLE forward, per layer max(MFMA time, HBM time)
             "layer_model_ms": t_model * 1e3, "layer_model_bytes_per_fwd": b_model,
             "frac_layer": t_model * 1e3 / fwd_ms,
         }
+        dk = result["roofline"]["dominant_kernel"]
+        if dom_l2 and dk and dk.get("us_per_launch_in_situ"):
+            result["roofline"]["l2_bytes_per_launch"] = dom_l2["bytes_per_launch"]
+            result["roofline"]["l2_frac"] = dom_l2["bytes_per_launch"] / (dk["us_per_launch_in_situ"] * 1e-6) / (PEAK_L2_TBS * 1e12)
+            result["roofline"]["l2_kernel"] = dom_l2["kernel"]
+            result["roofline"]["l2_hit_rate"] = dom_l2["hit_rate"]
         result["unet"] = {"fwd_ms_graph": fwd_ms, "body_ms_graph": body_ms, "algorithmic_gflop_per_fwd": flops_fwd / 1e9,
                           "mfma_util": flops_fwd / (fwd_ms * 1e-3) / (PEAK_MFMA_F16_TFLOPS * 1e12),
                           "kernel_launches_per_fwd": n_kernels,
