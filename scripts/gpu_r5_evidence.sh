@@ -12,7 +12,7 @@ for pass in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
   rm -rf /tmp/p5; timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d /tmp/p5 -o p -- python $R/scripts/fwd_replay.py 32 32 4 > /tmp/p5.log 2>&1 || tail -3 /tmp/p5.log
   f=$(find /tmp/p5 -name "*counter_collection.csv" | head -1)
   echo "## pass: $pass" >> $R/gpurun_out/r05_pmc_forward_kernels.txt
-  python $R/scripts/pmc_fwd_by_kernel.py "$f" "igemm_ws_kernel<1, 7, 4, 1, 4, 3" mlp_kernel hblock_kernel xblock_kernel attn_lds_kernel >> $R/gpurun_out/r05_pmc_forward_kernels.txt
+  python $R/scripts/pmc_fwd_by_kernel.py "$f" "igemm_ws_kernel<1, 7, 4, 1, 4, 3" mlp_kernel hblock_kernel xblock_kernel attn_ >> $R/gpurun_out/r05_pmc_forward_kernels.txt
   if echo "$pass" | grep -q TCC_HIT; then cp "$f" /tmp/p5_tcc.csv; fi
 done
 # fabric traffic (FETCH / WRITE) + the dominant kernel's L2 request bytes -> the summary bench.py reads
