@@ -533,6 +533,123 @@ static int attn_waves_per_block(const upk_ctx* ctx, int bh, int n_q, int qt) {
   return wpb;
 }
 
+// ---------------------------------------------------------------------------------------
+// Wide single-head attention: the VAE's mid-block AttnBlock (model.py:150-202: one head, d = 512, 1024 / 768 tokens).
+// attn_kernel<512> gives every wave of 16 queries its own pass over K and V^T through the CU's L1 — 2 MB per wave, 64
+// times per sample: 284 us per decode at B = 8 for 17 GFLOP (profiles/r04_optrace_vae_32x32.txt).  Here a workgroup of
+// four waves = 64 queries shares every 32-key tile through LDS:
+//   * the tile arrives by LDS-DMA (global_load_lds_dwordx4: 32 requests for K, 32 for V^T, 16 per wave), double
+//     buffered: tile t + 1 is on its way while the waves work on tile t, one workgroup barrier per tile;
+//   * K tile [32 keys][1024 + 32 bytes] (row stride 32 mod 64: conflict-free 16-byte fragment reads), V^T tile
+//     [512 rows][64 bytes] with the four 16-byte pieces of a row XOR-swizzled by (row >> 2) & 3 on the SOURCE side of
+//     the DMA (the 32 lanes of an 8-byte read group then fall on 32 different 8-byte slots);
+//   * per wave: Q fragments (64 registers) and the 16 x 512 output (128 registers) stay in registers, S^T / P as in
+//     attn_tile (key permutation 8 g + 4 t + r -> 16 t + 4 g + r).
+// Bytes: a workgroup streams K + V^T once (2 MB) for 64 queries instead of once per 16: 268 MB through the L2s per
+// decode instead of 1 GB, and the 65 MFMAs a wave issues per tile stand behind LDS, not L2, latency.
+template <int D>
+__global__ __launch_bounds__(256) void attn_wide_kernel(const AttnArgs a) {
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* glb_ptr;
+  constexpr int KD = D / 32, DT = D / 16;
+  constexpr int KROW = D * 2 + 32;         // bytes per staged K row
+  constexpr int KBYTES = 32 * KROW;        // K tile
+  constexpr int VBYTES = D * 64;           // V^T tile: D rows x 32 keys
+  constexpr int BUF = KBYTES + VBYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int b = blockIdx.x;  // (one head: a sample per grid column; its query blocks go to one XCD when the batch is a multiple of 8)
+  const int q0 = (blockIdx.y * 4 + wave) * 16;
+  const f16* kg = a.k + b * a.kbs;
+  const f16* vg = a.vt + (long)b * D * a.vt_ld;
+  auto issue = [&](int kb, int buf) {
+    char* base = smem + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // K: row r of the tile = 64 lanes x 16 bytes (D = 512: exactly one request)
+      const int r = wave + 4 * i;
+      const f16* src = kg + (long)(kb + r) * a.ldk + lane * 8;
+      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(base + r * KROW), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < D / 64; ++i) {  // V^T: 16 rows x 64 bytes per request, pieces swizzled at the source
+      const int rb = (wave + 4 * i) * 16;  // first row of this request
+      const int row = rb + (lane >> 2), pc = (lane & 3) ^ ((row >> 2) & 3);
+      const f16* src = vg + (long)row * a.vt_ld + kb + pc * 8;
+      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(base + KBYTES + rb * 64), 16, 0, 0);
+    }
+  };
+  issue(0, 0);
+  const bool q_ok = q0 + c < a.nq;
+  const f16* qrow = a.q + b * a.qbs + (long)(q_ok ? q0 + c : 0) * a.ldq + g * 8;
+  f16x8 qf[KD];
+#pragma unroll
+  for (int kd = 0; kd < KD; ++kd) qf[kd] = q_ok ? *(const f16x8*)(qrow + kd * 32) : (f16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  f32x4 o[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 lsum = {0.f, 0.f, 0.f, 0.f};
+  float mrun = -INFINITY;
+  const float cs = a.scale_log2;
+  const int ntiles = a.nkv >> 5;
+  const int vsw = (c >> 2) & 3;  // swizzle of this lane's V^T rows (16 i + c)
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's requests for tile t have landed
+    __syncthreads();                                  // ... everybody's have, and everybody is done with tile t - 1
+    if (t + 1 < ntiles) issue((t + 1) << 5, buf ^ 1);
+    const char* kt = smem + buf * BUF + c * KROW + g * 16;
+    const char* vt = smem + buf * BUF + KBYTES + c * 64;
+    f32x4 sc[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      sc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kd = 0; kd < KD; ++kd) {
+        const f16x8 kf = *(const f16x8*)(kt + tt * 16 * KROW + kd * 64);
+        sc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kd], sc[tt], 0, 0, 0);
+      }
+    }
+    float mx = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])),
+                     fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
+    mx = max_over_key_groups(mx);
+    const float mnew = fmaxf(mrun, mx);
+    if (__builtin_amdgcn_ballot_w64(mnew != mrun) != 0) {
+      const float alpha = raw_exp2((mrun - mnew) * cs);
+      lsum *= alpha;
+#pragma unroll
+      for (int i = 0; i < DT; ++i) o[i] *= alpha;
+    }
+    mrun = mnew;
+    const float mc = -mnew * cs;
+    f16x8 pf;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pf[tt * 4 + r] = (f16)raw_exp2(fmaf(sc[tt][r], cs, mc));
+    lsum = __builtin_amdgcn_mfma_f32_16x16x32_f16(ATT_ONES, pf, lsum, 0, 0, 0);
+    // V^T fragment of rows 16 i + c: keys 4 g .. 4 g + 3 (piece g >> 1, half g & 1) and 16 + 4 g .. (piece 2 + (g >> 1))
+#pragma unroll
+    for (int i = 0; i < DT; ++i) {
+      const char* vr = vt + i * 16 * 64 + (g & 1) * 8;
+      const f16x4 va = *(const f16x4*)(vr + (((g >> 1) ^ vsw) << 4));
+      const f16x4 vb = *(const f16x4*)(vr + (((2 + (g >> 1)) ^ vsw) << 4));
+      const f16x8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+      o[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[i], 0, 0, 0);
+    }
+  }
+  if (!q_ok) return;
+  const float inv = 1.0f / lsum[0];
+  f16* orow = a.o + b * a.obs + (long)(q0 + c) * a.ldo + g * 4;
+#pragma unroll
+  for (int i = 0; i < DT; ++i) {
+    f16x4 ov;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ov[r] = (f16)(o[i][r] * inv);
+    *(f16x4*)(orow + i * 16) = ov;
+  }
+}
+
 static int attention_impl(upk_ctx* ctx, const void* q, int ldq, long long qbs, const void* k, int ldk, long long kbs,
                           const void* vt, int vt_ld, void* out, int ldo, long long obs, int batch, int heads, int n_q,
                           int n_kv, int d, float scale, int causal, upk_stream stream_) {
@@ -598,8 +715,19 @@ static int attention_impl(upk_ctx* ctx, const void* q, int ldq, long long qbs, c
     case 32: UPK_ATTN(32, 1) break;
     case 64: UPK_ATTN(64, 1) break;
     case 128: UPK_ATTN(128, 1) break;
-    case 256:
-    case 512: {
+    case 512:
+      // the VAE mid-block attention on LDS-shared key tiles (attn_wide_kernel): one head, whole 32-key tiles, rows of K
+      // that are exactly one 1 KiB request; anything else falls through to the direct kernel below
+      if (heads == 1 && !causal && (n_kv & 31) == 0 && ldk >= 512 && (vt_ld & 7) == 0 && !getenv("UPK_ATTN_WIDE_OFF")) {
+        static unsigned long long wide_mask = 0;
+        int rcw = upk_lds_attr_once(ctx, (const void*)attn_wide_kernel<512>, &wide_mask);
+        if (rcw != UPK_OK) return rcw;
+        const size_t lds = 2 * (32 * (512 * 2 + 32) + 512 * 64);
+        hipLaunchKernelGGL((attn_wide_kernel<512>), dim3(batch, (n_q + 63) / 64), dim3(256), lds, stream, a);
+        return upk_check_launch(ctx, "attention_wide");
+      }
+      [[fallthrough]];
+    case 256: {
       // the VAE mid-block attention (one head, d = 512, 1024 tokens: model.py:180-196): every wave streams the whole K / V^T
       // of its sample through the CU's vector-memory path, so fewer waves per workgroup until every CU has work
       // (B = 8: 128 workgroups of 4 waves -> 512 of 1)
