@@ -4,11 +4,11 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("UPGPT_XCD_VERBOSE", "1")
 import upgpt_amd
-from upgpt_amd import engine, synth
+from upgpt_amd import engine, knobs, synth
 kind = sys.argv[1] if len(sys.argv) > 1 else "tiny"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 hw = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (32, 24)
-engine.XCD = "1"
+knobs.XCD = "1"
 with contextlib.redirect_stdout(io.StringIO()):
     model = upgpt_amd.build_model(kind)
 synth.fill_module_(model); model = model.cuda()
@@ -16,7 +16,7 @@ unet = model.model.diffusion_model
 inp = synth.synth_inputs(B, hw, 4, 87, 768, seed=11)
 x = torch.cat([inp["x_T"], inp["c_concat"]], 1).cuda(); t = (torch.arange(B) * 100 + 1).cuda(); c = inp["c_crossattn"].cuda()
 def run(mode):
-    engine.XCD = mode
+    knobs.XCD = mode
     for pl in unet._plans.values(): pl.close()
     unet._plans.clear()
     eps = unet(x, t, context=c)

@@ -83,11 +83,11 @@ def test_unet_forward_with_and_without_the_fused_mlp():
     chip) against the two-launch path (UPGPT_MLP_FUSE=0), same weights and inputs."""
     import importlib
     import upgpt_amd
-    from upgpt_amd import engine, synth
+    from upgpt_amd import knobs, synth
 
     def run(mode):
-        old = engine.MLP_FUSE
-        engine.MLP_FUSE = mode
+        old = knobs.MLP_FUSE
+        knobs.MLP_FUSE = mode
         try:
             m = upgpt_amd.build_model("bbox")
             synth.fill_module_(m)
@@ -99,7 +99,7 @@ def test_unet_forward_with_and_without_the_fused_mlp():
             pl = next(iter(m.model.diffusion_model._plans.values()))
             return eps.float().cpu(), sum(1 for lab in pl.body.labels if lab.startswith("mlp "))
         finally:
-            engine.MLP_FUSE = old
+            knobs.MLP_FUSE = old
 
     e1, n1 = run("auto")
     e0, n0 = run("0")

@@ -106,11 +106,11 @@ def test_unet_forward_with_and_without_the_fused_cross_block():
     """The bbox UNet at the bench shape (B = 8, 32x32): eps with the fused cross-attention half against the unfused
     launches (UPGPT_XBLOCK=0), same weights and inputs."""
     import upgpt_amd
-    from upgpt_amd import engine, synth
+    from upgpt_amd import knobs, synth
 
     def run(mode):
-        old = engine.XBLOCK
-        engine.XBLOCK = mode
+        old = knobs.XBLOCK
+        knobs.XBLOCK = mode
         try:
             m = upgpt_amd.build_model("bbox")
             synth.fill_module_(m)
@@ -122,7 +122,7 @@ def test_unet_forward_with_and_without_the_fused_cross_block():
             pl = next(iter(m.model.diffusion_model._plans.values()))
             return eps.float().cpu(), sum(1 for lab in pl.body.labels if lab.startswith("xblock "))
         finally:
-            engine.XBLOCK = old
+            knobs.XBLOCK = old
 
     e1, n1 = run("1")
     e0, n0 = run("0")
@@ -225,11 +225,11 @@ def test_head_block_groupnorm_fold_is_bit_identical_to_the_launch(ctx, B, hw, ro
 
 def test_unet_forward_with_and_without_the_fused_head():
     import upgpt_amd
-    from upgpt_amd import engine, synth
+    from upgpt_amd import knobs, synth
 
     def run(mode):
-        old = engine.HBLOCK
-        engine.HBLOCK = mode
+        old = knobs.HBLOCK
+        knobs.HBLOCK = mode
         try:
             m = upgpt_amd.build_model("bbox")
             synth.fill_module_(m)
@@ -241,7 +241,7 @@ def test_unet_forward_with_and_without_the_fused_head():
             pl = next(iter(m.model.diffusion_model._plans.values()))
             return eps.float().cpu(), sum(1 for lab in pl.body.labels if lab.startswith("hblock "))
         finally:
-            engine.HBLOCK = old
+            knobs.HBLOCK = old
 
     e1, n1 = run("auto")
     e0, n0 = run("0")
@@ -258,7 +258,7 @@ def test_head_block_behind_a_split_k_producer():
     with the separate-GroupNorm reference path (HBLOCK_GN off)."""
     import ctypes as C
     import upgpt_amd
-    from upgpt_amd import engine, synth
+    from upgpt_amd import knobs, synth
     m = upgpt_amd.build_model("bbox")
     synth.fill_module_(m)
     m = m.cuda()
@@ -268,8 +268,8 @@ def test_head_block_behind_a_split_k_producer():
     unet = m.model.diffusion_model
 
     def run(gn_fold, force_split):
-        old = engine.HBLOCK_GN
-        engine.HBLOCK_GN = gn_fold
+        old = knobs.HBLOCK_GN
+        knobs.HBLOCK_GN = gn_fold
         try:
             for pl in unet._plans.values():
                 pl.close()
@@ -289,7 +289,7 @@ def test_head_block_behind_a_split_k_producer():
             eps = m.apply_model(inp["x_T"].cuda(), t, cond)
             return eps.float().cpu(), forced
         finally:
-            engine.HBLOCK_GN = old
+            knobs.HBLOCK_GN = old
 
     e_ref, _ = run(False, False)
     e_m3, forced = run(True, True)

@@ -1,0 +1,32 @@
+"""Environment switches of the lowering (read at import; tests and tuning scripts flip the attributes of THIS module)."""
+import os
+
+# GroupNorm statistics of the VAE decoder's tensors as conv by-products (gn_stats_cap + upk_groupnorm_finalize_f32):
+# measured neutral (8.29 vs 8.29 ms per decode) — the statistics pass runs at 5.6 TB/s since round 2, the channel
+# partials cost the 200-us convs 2-3 % and a 32-block fold per apply workgroup more than the pass it replaces — off
+VAE_GN_BYPRODUCT = os.environ.get("UPGPT_VAE_GN_BYPRODUCT", "0") == "1"
+UPS_PHASES = os.environ.get("UPGPT_UPS_PHASES", "1") == "1"
+LN_ROWS = os.environ.get("UPGPT_LN_ROWS", "1") == "1"
+QPROJ_FUSE = os.environ.get("UPGPT_QPROJ_FUSE", "1") == "1"
+GN_REDUCE_APPLY = os.environ.get("UPGPT_GN_REDUCE_APPLY", "1") == "1"
+# fused feed-forward tail (csrc/mlp.hip: GEGLU -> ff.net.2 o proj_out with the hidden activation in LDS): "auto" = where
+# M / rows-per-workgroup covers the chip (the 32x32 level at B = 8), "0" off, "1" wherever the kernel takes the shape
+MLP_FUSE = os.environ.get("UPGPT_MLP_FUSE", "auto")
+MLP_ROWS = int(os.environ.get("UPGPT_MLP_ROWS", "0"))  # rows per workgroup (32 / 64; 0 = by M)
+# fused cross-attention half of a transformer block (csrc/xblock.hip: attn1.to_out -> norm2 -> to_q -> attention over the
+# context -> attn2.to_out, one launch instead of three / four): "auto", "0" off, "1" wherever the kernel takes the shape
+XBLOCK = os.environ.get("UPGPT_XBLOCK", "auto")
+XB_ROWS = int(os.environ.get("UPGPT_XB_ROWS", "0"))  # rows per workgroup (16 / 32; 0 = by M)
+# fused head of a SpatialTransformer (csrc/xblock.hip hblock_kernel: proj_in -> norm1 -> q | k | v, one launch instead of two)
+HBLOCK = os.environ.get("UPGPT_HBLOCK", "auto")
+HBLOCK_GN = os.environ.get("UPGPT_HBLOCK_GN", "1") == "1"  # SpatialTransformer.norm applied on the tile inside that launch
+# per-XCD persistent engine (csrc/xcd.hip, include/upk.h upk_xcd_run_f16): a whole SpatialTransformer as ONE launch, sample b
+# on XCD b % 8, XCD-local barriers (1.04 us measured) between its ten phases.  Built, parity-green and measured in round 5
+# (DESIGN.md 12): inside the replayed forward a block costs 130 us on the engine against 95 us as a launch chain — every
+# phase re-stages its rows through the XCD's shared L2 and pays 2-3 L2 / HBM round trips of 1-2.5 us that a barrier cannot
+# hide — so it is OFF by default: "0" off, "1" wherever the engine takes the shape (any batch: the GPU tests), "auto" =
+# batches that are a multiple of 8 at feature maps of <= XCD_MAXN pixels.  UPGPT_XCD_SPLIT=1: one launch per phase.
+XCD = os.environ.get("UPGPT_XCD", "0")
+XCD_MAXN = int(os.environ.get("UPGPT_XCD_MAXN", "256"))
+XCD_SPLIT = os.environ.get("UPGPT_XCD_SPLIT", "0") == "1"
+LN_LAUNCH_US = 5.0  # what a separate LayerNorm launch costs inside the replayed forward (3.8 us of kernel + its boundary: DESIGN.md 11i / 11j)
