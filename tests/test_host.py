@@ -238,3 +238,38 @@ def test_xcd_gemm_grid_respects_the_engine_constraints():
             assert tn == 2 and tpc % 2 == 0, (g, ntiles)
         if wk > 1:
             assert tpc <= tn * (8 // wk), (g, ntiles)
+
+
+def test_tune_cache_guards_and_round_trip(tmp_path):
+    """TuneCache (upgpt_amd/tuning.py): put() before bind() is refused, malformed entries are dropped at bind,
+    entries are re-indexed by configuration NAME when the library's list changed, and save / load round-trips."""
+    import json
+    from upgpt_amd.tuning import TuneCache
+
+    class FakeLib:
+        names = [b"a", b"b", b"c"]
+
+        def upk_conv_num_configs(self):
+            return len(self.names)
+
+        def upk_conv_config_name(self, i):
+            return self.names[i]
+
+    f = tmp_path / "t.json"
+    json.dump({"__configs__": ["b", "zz", "a"], "k0": [0, 1, 5.0, 6.0], "k1": [1, 2, 5.0, 6.0], "k2": [2, 1, 5.0, 6.0],
+               "bad": "oops", "bad2": []}, open(f, "w"))
+    tc = TuneCache(str(f))
+    try:
+        tc.put("x", 0, 1, 1.0, 1.0)
+        assert False, "put before bind must be refused"
+    except RuntimeError:
+        pass
+    tc.bind(FakeLib())
+    assert tc.get("k0")[0] == 1 and tc.get("k2")[0] == 0  # "b" -> index 1, "a" -> index 0 in the new list
+    assert tc.get("k1") is None and tc.get("bad") is None and tc.get("bad2") is None  # "zz" is gone; junk dropped
+    tc.put("x", 2, 1, 1.0, 2.0)
+    out = tmp_path / "o.json"
+    tc.save(str(out))
+    tc2 = TuneCache(str(out))
+    tc2.bind(FakeLib())
+    assert tc2.get("x") == [2, 1, 1.0, 2.0] and tc2.get("k0")[0] == 1

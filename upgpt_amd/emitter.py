@@ -105,6 +105,10 @@ class Emitter:
                 missing += 1
             if ent is not None:
                 d.tune_cfg, d.tune_splitk = int(ent[0]) + 1, int(ent[1])
+        if tuned and cache.dirty and os.environ.get("UPGPT_TUNE_SAVE"):
+            # shapes outside the shipped table (another batch / latent size) were just measured on this device
+            # (UPGPT_AUTOTUNE=1): UPGPT_TUNE_SAVE=<path> keeps them for the next process (load with UPGPT_TUNE_FILE=<path>)
+            cache.save(os.environ["UPGPT_TUNE_SAVE"])
         return hits, tuned, missing
 
     def _is_as(self, cfg):
