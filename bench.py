@@ -15,6 +15,8 @@ in HBM.  value = images/s over all ranks.  The config-true 256x192 (latent 32x24
 reported next to it.
 """
 import argparse
+import contextlib
+import io
 import json
 import os
 import sys
@@ -93,6 +95,21 @@ def timed(fn, n, dev):
     sync()
     D.barrier()
     return time.perf_counter() - t0, out
+
+
+def timed_lanes(pool, step_fn, n, dev, after=None):
+    """EXACTLY n bench steps between barrier + device synchronisation on both sides, step k on execution lane
+    k % pool.n (upgpt_amd/lanes.py: each lane = own stream, own scratch and buffers, own host thread; the steps of a
+    lane run in order, steps of different lanes overlap on the device).  `after(k, images)` runs in step order on
+    every rank (the all-gather).  -> (seconds, result of the last step)."""
+    from upgpt_amd import dist as D
+    D.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    outs = pool.run(step_fn, n, after=after)
+    torch.cuda.synchronize(dev)
+    D.barrier()
+    return time.perf_counter() - t0, outs[-1]
 
 
 def gathered(step_fn):
@@ -475,6 +492,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--latent", default="32x32", help="HxW of the latent (32x32 = 256x256 px)")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("UPGPT_BENCH_LANES", "3")),
+                    help="independent bs=8 batches in flight per GPU (execution lanes, upgpt_amd/lanes.py); 1 = one batch "
+                         "at a time (the serial loop, also reported as `serial` when lanes > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--cfg", type=float, default=0.0,
@@ -506,13 +526,19 @@ def main():
     synth.fill_module_(model)
     model = model.cuda()
     log("[bench] rank %d model ready in %.1fs" % (rank, time.time() - t0))
-    wl = Workload(model, args.batch, hw, args.ddim_steps, seed=D.rank_seed(0, rank))
+    from upgpt_amd.lanes import LanePool
+    n_lanes = max(1, min(args.lanes, args.steps))
+    # one synthetic batch per lane (lane l of rank r: seed r + 1000 l), all resident in HBM before the timed region
+    wls = [Workload(model, args.batch, hw, args.ddim_steps, seed=D.rank_seed(1000 * l, rank)) for l in range(n_lanes)]
+    wl = wls[0]
+    pool = LanePool(n_lanes, dev)
+    step_k = lambda k: wls[k % n_lanes].run()
+    gather_k = lambda k, img: D.all_gather_images(img)
 
-    step = gathered(lambda: quiet(wl.run))
-
-    for _ in range(args.warmup):
-        step()
-    dt, out = timed(step, args.steps, dev)
+    with contextlib.redirect_stdout(io.StringIO()):  # (the sampler prints like the reference; stdout carries the JSON line)
+        # every lane builds its plans / graphs on its first step: warm each lane at least once, W steps in total at least
+        timed_lanes(pool, step_k, max(args.warmup, n_lanes), dev, after=gather_k)
+        dt, out = timed_lanes(pool, step_k, args.steps, dev, after=gather_k)
     dt = D.max_over_ranks(dt, dev)
     assert out.shape[0] == args.batch * world and torch.isfinite(out).all()
     images = args.batch * world * args.steps
@@ -525,11 +551,26 @@ def main():
                                "text-only cond [B,87,768], UNet(bbox.yaml) + VAE decode, EMA weights, no CFG" % (
                                    args.batch, hw[0] * 8, hw[1] * 8, hw[0], hw[1], args.ddim_steps),
                    "batch_per_gpu": args.batch, "ddim_steps": args.ddim_steps, "latent": list(hw),
+                   "batches_in_flight_per_gpu": n_lanes,
+                   "lanes": "%d execution lane(s) per GPU: every step is one sample(batch_size=%d) + decode call; step k runs on "
+                            "lane k %% %d (own HIP stream, own split-K workspace / activation buffers / step graphs, own host "
+                            "thread; packed weights shared), so up to %d independent batches overlap on the device"
+                            % (n_lanes, args.batch, n_lanes, n_lanes),
                    "parallelism": "replica-dp%d, one all-gather of images per batch" % world},
     }
+    if n_lanes > 1:
+        # the same steps one batch at a time (what `value` was through round 4): lane 0 alone, same barriers
+        ks = max(2, min(args.steps, 6))
+        with contextlib.redirect_stdout(io.StringIO()):
+            dts, _ = timed(gathered(wl.run), ks, dev)
+        dts = D.max_over_ranks(dts, dev)
+        result["serial"] = {"value": args.batch * world * ks / dts, "unit": "images/s", "steps": ks,
+                            "ms_per_step": dts / ks * 1e3, "batches_in_flight_per_gpu": 1}
+        result["step_latency_ms"] = dt / args.steps * 1e3 * n_lanes  # (a batch's own time in flight, approx.)
     if rank == 0:
         a = arch.UNetArch(**synth.BBOX_UNET)
         flops_fwd = a.flops(args.batch, hw[0], hw[1], 87)
+        result["mfma_util_whole_job"] = flops_fwd * args.ddim_steps * args.steps / dt / (PEAK_MFMA_F16_TFLOPS * 1e12)
         fwd_ms = unet_forward_ms(model, wl)
         prof, ig_flops, at_flops, n_kernels, body_ms = kernel_class_profile(model, wl)
         ig_ms = prof["igemm"]["ms_per_fwd"]

@@ -1,0 +1,124 @@
+"""Host logic of the execution lanes (upgpt_amd/lanes.py, _lib.lane): step -> lane assignment, per-lane order, the
+in-order `after` hook, error propagation, the lane-keyed plan caches, the re-entrant ema_scope, and — world size 2 over
+gloo — that an exchange issued from `after` pairs up across ranks whatever the lanes' relative speed."""
+import os
+import socket
+import threading
+import time
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from upgpt_amd import _lib as L
+from upgpt_amd.lanes import LanePool, step_lane
+
+
+def test_lane_context_is_thread_local_and_nests():
+    assert L.current_lane() == 0
+    seen = {}
+    with L.lane(2):
+        assert L.current_lane() == 2
+        with L.lane(1):
+            assert L.current_lane() == 1
+        assert L.current_lane() == 2
+        t = threading.Thread(target=lambda: seen.setdefault("other", L.current_lane()))
+        t.start(); t.join()
+    assert L.current_lane() == 0 and seen["other"] == 0
+    with pytest.raises(ValueError):
+        with L.lane(-1):
+            pass
+
+
+@pytest.mark.parametrize("n,K", [(1, 5), (2, 7), (3, 3), (3, 20), (4, 2)])
+def test_pool_runs_step_k_on_lane_k_mod_n_in_lane_order_and_after_in_step_order(n, K):
+    pool = LanePool(n, "cpu")
+    ran, after_order = [], []
+    lock = threading.Lock()
+
+    def fn(k):
+        time.sleep(0.002 * ((k * 7) % 3))  # (lanes finish out of step order)
+        with lock:
+            ran.append((k, L.current_lane()))
+        return k * 10
+
+    outs = pool.run(fn, K, after=lambda k, r: after_order.append(k) or r + 1)
+    assert outs == [k * 10 + 1 for k in range(K)]
+    assert after_order == list(range(K))
+    assert sorted(ran) == [(k, step_lane(k, n)) for k in range(K)]
+    for i in range(n):  # the steps of one lane ran in order
+        mine = [k for k, l in ran if l == i]
+        assert mine == sorted(mine)
+    assert pool.run(fn, K) == [k * 10 for k in range(K)]
+
+
+def test_pool_reraises_a_lane_error_on_the_caller():
+    pool = LanePool(3, "cpu")
+
+    def fn(k):
+        if k == 4:
+            raise KeyError("step 4")
+        return k
+
+    with pytest.raises(KeyError):
+        pool.run(fn, 9)
+    assert pool.run(lambda k: k, 3) == [0, 1, 2]  # (the pool is usable afterwards)
+
+
+def test_ema_scope_is_reentrant_across_threads():
+    import upgpt_amd
+    m = upgpt_amd.build_model("tiny")
+    unet = m.model.diffusion_model
+    inside = threading.Barrier(3)
+    states = []
+
+    def worker():
+        with m.ema_scope():
+            inside.wait()
+            states.append(unet._weight_override is not None)
+            inside.wait()
+
+    th = [threading.Thread(target=worker) for _ in range(2)]
+    for t in th:
+        t.start()
+    inside.wait()          # both workers are inside
+    with m.ema_scope():    # nested entry from a third thread
+        assert unet._weight_override is not None
+    assert unet._weight_override is not None  # the workers still hold it
+    inside.wait()
+    for t in th:
+        t.join()
+    assert states == [True, True] and unet._weight_override is None
+
+
+def _gloo_rank(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from upgpt_amd import dist as D
+    pool = LanePool(3, "cpu")
+
+    def fn(k):  # the ranks' lanes run at different speeds
+        time.sleep(0.003 * ((k * (5 if rank else 3)) % 4))
+        return torch.full((2, 3), float(100 * rank + k))
+
+    outs = pool.run(fn, 8, after=lambda k, img: D.all_gather_images(img))
+    q.put((rank, [o[:, 0].tolist() for o in outs]))
+    dist.destroy_process_group()
+
+
+def test_all_gather_from_the_after_hook_pairs_up_across_two_ranks():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_gloo_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in range(2):  # step k of every rank met step k of the other one
+        assert got[r] == [[float(k)] * 2 + [float(100 + k)] * 2 for k in range(8)]

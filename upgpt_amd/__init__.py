@@ -7,6 +7,13 @@ from .config import instantiate_from_config, load_config  # noqa: F401
 __version__ = "0.1.0"
 
 
+def lane(i, stream=None):
+    """Execution lane `i` for the calling thread (context manager; upgpt_amd._lib.lane): batches sampled in different
+    lanes may be in flight on one GPU at the same time — own scratch, own buffers, shared weights."""
+    from ._lib import lane as _lane
+    return _lane(i, stream)
+
+
 def model_params(kind="bbox", overrides=None):
     """Constructor kwargs of LatentDiffusion for the restated reference configs in synth.py (`bbox`, `upscale`, `tiny`),
     conditioning stages replaced by DummyModel (embeddings fed directly)."""

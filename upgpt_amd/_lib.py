@@ -4,6 +4,7 @@ The product path has NO CPU fallback: if the HIP library is missing, was not
 built for gfx950, or no MI355X is visible, the calls raise.  PyTorch is used
 only for device memory, streams and (elsewhere) torch.distributed.
 """
+import contextlib
 import ctypes as C
 import os
 import threading
@@ -397,13 +398,45 @@ class Context:
 
 
 _ctxs = {}
+_ctx_lock = threading.Lock()
+PLAN_LOCK = threading.RLock()  # plan / packed-weight caches are built under it (lanes share the model objects)
+_lane = threading.local()
 
 
-def get_context(device=None):
+def current_lane():
+    """Index of the execution lane of the calling thread (0 unless inside `lane(i)`)."""
+    return getattr(_lane, "i", 0)
+
+
+@contextlib.contextmanager
+def lane(i, stream=None):
+    """Everything the calling thread launches inside this block belongs to execution lane `i`: its own upk_ctx (own
+    split-K workspace), its own activation buffers / plans / captured graphs (the plan caches of UNetModel and
+    AutoencoderKL are keyed by lane) and, when `stream` is given, that HIP stream.  The packed weights are shared.
+    Two lanes never touch the same scratch memory, so two batches may be in flight on the device at once — the
+    kernels of one lane's latency chain fill the launch boundaries and prologues of the other's.
+    Lane 0 is the default lane: code that never enters a lane behaves exactly as before."""
+    require(int(i) >= 0, "lane index must be >= 0", ValueError)
+    prev = getattr(_lane, "i", 0)
+    _lane.i = int(i)
+    try:
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                yield
+        else:
+            yield
+    finally:
+        _lane.i = prev
+
+
+def get_context(device=None, lane=None):
     idx = torch.cuda.current_device() if device is None else (
         device.index if isinstance(device, torch.device) else int(device))
     if idx is None:
         idx = torch.cuda.current_device()
-    if idx not in _ctxs:
-        _ctxs[idx] = Context(idx)
-    return _ctxs[idx]
+    key = (idx, current_lane() if lane is None else int(lane))
+    if key not in _ctxs:
+        with _ctx_lock:
+            if key not in _ctxs:
+                _ctxs[key] = Context(idx)
+    return _ctxs[key]

@@ -13,6 +13,7 @@ those keyword arguments are accepted and ignored, the training entry points rais
 
 Plain torch.nn.Modules (no pytorch_lightning); every FLOP of the denoiser / first stage runs in the HIP engine.
 """
+import threading
 from contextlib import contextmanager
 
 import numpy as np
@@ -24,6 +25,9 @@ from .ddim import DDIMSampler
 from .ema import LitEma
 from .schedule import extract_into_tensor, make_beta_schedule
 from ._check import require
+
+
+_EMA_LOCK = threading.Lock()
 
 
 def disabled_train(self, mode=True):
@@ -155,15 +159,24 @@ class DDPM(nn.Module):
         if not self.use_ema:
             yield None
             return
+        # the scope nests and may be entered from several host threads at once (one per execution lane): the override
+        # goes in with the first entrant and out with the last
         unet, ema = self.model.diffusion_model, self.model_ema
-        unet.set_weight_override("ema", lambda n: ema.shadow("diffusion_model." + n).data,
-                                 lambda: (sum(b._version for b in ema.buffers()), ema.decay.data_ptr()))
+        with _EMA_LOCK:
+            n = self.__dict__.get("_ema_depth", 0)
+            if n == 0:
+                unet.set_weight_override("ema", lambda n: ema.shadow("diffusion_model." + n).data,
+                                         lambda: (sum(b._version for b in ema.buffers()), ema.decay.data_ptr()))
+            self.__dict__["_ema_depth"] = n + 1
         if context is not None:
             print(f"{context}: Switched to EMA weights")
         try:
             yield None
         finally:
-            unet.set_weight_override(None)
+            with _EMA_LOCK:
+                n = self.__dict__["_ema_depth"] = self.__dict__["_ema_depth"] - 1
+                if n == 0:
+                    unet.set_weight_override(None)
             if context is not None:
                 print(f"{context}: Restored training weights")
 

@@ -31,7 +31,7 @@ class UNetModel(ParamTree):
         self.predict_codebook_ids = False
         self.add_params(a.param_shapes())
         self._packed = {}     # tag -> (fingerprint, PackedUNet)
-        self._plans = {}      # (tag, B, H, W, n_ctx, rows, mode) -> UNetPlan
+        self._plans = {}      # (tag, B, H, W, n_ctx, rows, mode, lane) -> UNetPlan
         self._weight_override = None  # (tag, callable name -> tensor): EMA weights without copying
 
     # ---- engine plumbing
@@ -49,6 +49,11 @@ class UNetModel(ParamTree):
         self._weight_override = None if tag is None else (tag, getter, fingerprint)
 
     def packed(self):
+        from ._lib import PLAN_LOCK
+        with PLAN_LOCK:
+            return self._packed_locked()
+
+    def _packed_locked(self):
         from ._lib import get_context
         from .engine import PackedUNet
         dev = self._device()
@@ -70,12 +75,18 @@ class UNetModel(ParamTree):
         return ctx, tag, self._packed[tag][1]
 
     def plan(self, B, H, W, n_ctx, rows, mode):
+        from ._lib import PLAN_LOCK
+        with PLAN_LOCK:
+            return self._plan_locked(B, H, W, n_ctx, rows, mode)
+
+    def _plan_locked(self, B, H, W, n_ctx, rows, mode):
+        from ._lib import current_lane
         from .engine import UNetPlan
-        ctx, tag, pk = self.packed()
-        key = (tag, B, H, W, n_ctx, rows, mode)
+        ctx, tag, pk = self.packed()  # (ctx = the calling thread's lane: own workspace, own buffers; weights shared)
+        key = (tag, B, H, W, n_ctx, rows, mode, current_lane())
         pl = self._plans.get(key)
         if pl is None:
-            if len(self._plans) >= 8:  # bound device memory held by stale shapes
+            if len(self._plans) >= 16:  # bound device memory held by stale shapes (a shape counts once per lane)
                 self._plans.pop(next(iter(self._plans))).close()
             with torch.cuda.device(ctx.device):
                 pl = UNetPlan(ctx, pk, B, H, W, n_ctx, rows, mode)

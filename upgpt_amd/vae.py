@@ -79,6 +79,11 @@ class AutoencoderKL(ParamTree):
         print(f"Restored from {path}")
 
     def _decode_plan(self, B, h, w, scale_factor):
+        from ._lib import PLAN_LOCK
+        with PLAN_LOCK:
+            return self._decode_plan_locked(B, h, w, scale_factor)
+
+    def _decode_plan_locked(self, B, h, w, scale_factor):
         from ._lib import get_context
         from .engine import PackedVAEDecoder, VAEDecodePlan
         p = next(self.parameters())
@@ -92,9 +97,10 @@ class AutoencoderKL(ParamTree):
             with torch.cuda.device(p.device):
                 self._packed = (fp, PackedVAEDecoder(ctx, self.arch, lambda n: params[n].data))
             self._plans = {}
-        key = (B, h, w, float(scale_factor))
+        from ._lib import current_lane
+        key = (B, h, w, float(scale_factor), current_lane())
         if key not in self._plans:
-            if len(self._plans) >= 4:
+            if len(self._plans) >= 8:
                 self._plans.pop(next(iter(self._plans)))
             with torch.cuda.device(p.device):
                 self._plans[key] = VAEDecodePlan(ctx, self._packed[1], B, h, w, scale_factor)
@@ -111,6 +117,11 @@ class AutoencoderKL(ParamTree):
             return pl.run(z).clone()
 
     def _encode_plan(self, B, H, W):
+        from ._lib import PLAN_LOCK
+        with PLAN_LOCK:
+            return self._encode_plan_locked(B, H, W)
+
+    def _encode_plan_locked(self, B, H, W):
         from ._lib import get_context
         from .engine import PackedVAEEncoder, VAEEncodePlan
         p = next(self.parameters())
@@ -124,9 +135,10 @@ class AutoencoderKL(ParamTree):
             with torch.cuda.device(p.device):
                 self._packed_enc = (fp, PackedVAEEncoder(ctx, self.arch, lambda n: params[n].data))
             self._enc_plans = {}
-        key = (B, H, W)
+        from ._lib import current_lane
+        key = (B, H, W, current_lane())
         if key not in self._enc_plans:
-            if len(self._enc_plans) >= 4:
+            if len(self._enc_plans) >= 8:
                 self._enc_plans.pop(next(iter(self._enc_plans)))
             with torch.cuda.device(p.device):
                 self._enc_plans[key] = VAEEncodePlan(ctx, self._packed_enc[1], B, H, W)
