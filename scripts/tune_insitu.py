@@ -22,6 +22,13 @@ TOPK = int(os.environ.get("INSITU_TOPK", "14"))
 VAE = os.environ.get("INSITU_VAE", "0") == "1"  # tune the VAE decoder (B = 8, latent HxW) instead of the UNet forward
 KIND = os.environ.get("INSITU_KIND", "bbox")     # "upscale": the upscale UNet (3 + 3 channels, 86 tokens)
 BATCH = int(os.environ.get("INSITU_B", "8"))     # 16 = the classifier-free-guidance pass over [uncond ; cond]
+LANES = int(os.environ.get("INSITU_LANES", "1"))  # > 1: tune for THROUGHPUT with that many forwards in flight (execution
+                                                 # lanes, upgpt_amd/lanes.py): the replay time is that of LANES captured
+                                                 # forwards replayed concurrently on LANES streams, per forward
+if LANES > 1:
+    from upgpt_amd import _lib
+    from upgpt_amd.tuning import TUNE_CACHE_LANES
+    _lib.set_concurrency(LANES)  # (the plans start from the throughput overlay; the output is the updated overlay)
 with contextlib.redirect_stdout(io.StringIO()):
     model = upgpt_amd.build_model(KIND, overrides={"image_size": [H, W]}) if KIND == "upscale" else upgpt_amd.build_model("bbox")
 synth.fill_module_(model); model = model.cuda()
@@ -38,6 +45,16 @@ pl.load_context(inp["c_crossattn"].cuda()); pl.t_rows.copy_(torch.arange(981, 0,
 pl.prep.run()
 st = SamplerState(pl, CH); st.x.copy_(inp["x_T"].cuda()); st.coefs.fill_(0.5)
 ctx = pl.ctx
+lane_plans, lane_states, lane_streams = [pl], [st], [torch.cuda.current_stream()]
+for i in range(1, LANES):
+    with upgpt_amd.lane(i):
+        p2 = unet.plan(BATCH, H, W, NTOK, 50, "sampler")
+        p2.load_x_nchw(inp["x_T"].cuda(), 0, 0); p2.load_x_nchw(inp["c_concat"].cuda(), CH, p2.cin_pad)
+        p2.load_context(inp["c_crossattn"].cuda()); p2.t_rows.copy_(torch.arange(981, 0, -20, dtype=torch.float32)[:50])
+        p2.prep.run()
+        s2 = SamplerState(p2, CH); s2.x.copy_(inp["x_T"].cuda()); s2.coefs.fill_(0.5)
+    lane_plans.append(p2); lane_states.append(s2); lane_streams.append(torch.cuda.Stream())
+torch.cuda.synchronize()
 ncfg = ctx.lib.upk_conv_num_configs()
 names = [ctx.lib.upk_conv_config_name(i).decode() for i in range(ncfg)]
 ONLY = os.environ.get("INSITU_ONLY", "")
@@ -54,6 +71,8 @@ def replay_ms():
             for _ in range(max(2, REPS // 3)): vp.prog.run()
             torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / max(2, REPS // 3) * 1e3)
         return best
+    if LANES > 1:
+        return replay_lanes_ms()
     for g in list(st.graphs.values()):
         ctx.graph_destroy(g)
     st.graphs.clear()
@@ -67,13 +86,44 @@ def replay_ms():
     return best
 
 
+def replay_lanes_ms():
+    """LANES forwards in flight: every lane's graph re-captured with the current descriptors, then REPS replays per lane
+    enqueued round robin on the lanes' streams; wall time per forward."""
+    gs = []
+    for i, (p, s_, strm) in enumerate(zip(lane_plans, lane_states, lane_streams)):
+        for g in list(s_.graphs.values()):
+            p.ctx.graph_destroy(g)
+        s_.graphs.clear()
+        with upgpt_amd.lane(i, strm):
+            gs.append(s_.graph(False))
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        for p in lane_plans:
+            p.step.zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(REPS):
+            for p, g, strm in zip(lane_plans, gs, lane_streams):
+                p.ctx._chk(p.lib.upk_graph_launch(p.hctx, g, strm.cuda_stream))
+        torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / (REPS * LANES) * 1e3)
+    return best
+
+
 # body convs only (the plan's conv list also holds the step-invariant prep launches)
-body = set(id(k) for k in (vp.prog.keep if VAE else pl.body.keep))
 groups = {}
-for d, key in (vp.convs if VAE else pl.convs):
-    if id(d) in body:
-        groups.setdefault(key, []).append(d)
-NOISE = 0.004 if VAE else 0.0015
+if VAE:
+    body = set(id(k) for k in vp.prog.keep)
+    for d, key in vp.convs:
+        if id(d) in body:
+            groups.setdefault(key, []).append(d)
+else:
+    for p in lane_plans:  # (the same shape is pinned to the same choice in every lane)
+        body = set(id(k) for k in p.body.keep)
+        for d, key in p.convs:
+            if id(d) in body:
+                groups.setdefault(key, []).append(d)
+NOISE = 0.004 if VAE else (0.006 if LANES > 1 else 0.0015)  # (concurrent replays are noisier)
 print("shapes in the forward:", len(groups), "launch descriptors:", sum(len(v) for v in groups.values()), flush=True)
 base = replay_ms()
 print("baseline forward %.4f ms" % base, flush=True)
@@ -167,9 +217,9 @@ for key in sorted(groups, key=share, reverse=True):
             cur = t_old
 final = replay_ms()
 print("forward %.4f -> %.4f ms, %d shapes changed" % (base, final, len(changed)))
-ent = dict(TUNE_CACHE.d)
+ent = dict(TUNE_CACHE_LANES.d) if LANES > 1 else dict(TUNE_CACHE.d)
 for key, (start, best, t_old, t_new) in changed.items():
-    old = ent.get(key) or ent.get(key[:-3]) or [0, 1, 0.0, 0.0]
+    old = ent.get(key) or ent.get(key[:-3]) or TUNE_CACHE.get(key) or [0, 1, 0.0, 0.0]
     ent[key] = [best[0], best[1], old[2], old[3]]
 ent["__configs__"] = names  # (the indices refer to THIS library's configuration list: TuneCache.bind)
 json.dump(ent, open(out, "w"), indent=0, sort_keys=True)

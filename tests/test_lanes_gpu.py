@@ -46,9 +46,9 @@ def test_batches_in_flight_are_bit_identical_to_one_at_a_time(kind, B, hw, S, et
     model = get_model(kind)
     K = 2 * lanes
     jobs = [job(model, B, hw, S, seed=40 + k, eta=eta) for k in range(K)]
+    pool = LanePool(lanes)  # (from here on plans take the launch choices tuned for a shared chip: serial run included)
     serial = [j() for j in jobs]  # lane 0, one batch at a time
     torch.cuda.synchronize()
-    pool = LanePool(lanes)
     seen = []
 
     def step(k):

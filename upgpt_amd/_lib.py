@@ -403,6 +403,20 @@ PLAN_LOCK = threading.RLock()  # plan / packed-weight caches are built under it 
 _lane = threading.local()
 
 
+_concurrency = 1
+
+
+def concurrency():
+    """How many batches the process keeps in flight per device (1 unless a LanePool with more lanes exists): plans
+    built at concurrency > 1 take the throughput-tuned launch choices (tuning.TUNE_CACHE_LANES)."""
+    return _concurrency
+
+
+def set_concurrency(n):
+    global _concurrency
+    _concurrency = max(1, int(n))
+
+
 def current_lane():
     """Index of the execution lane of the calling thread (0 unless inside `lane(i)`)."""
     return getattr(_lane, "i", 0)

@@ -29,11 +29,19 @@ extern "C" int upk_create(upk_ctx** out, int device) {
     int cur = 0;
     (void)hipGetDevice(&cur);
     (void)hipSetDevice(device);
-    if (hipMalloc(&c->zero_page, 4096) != hipSuccess || hipMemset(c->zero_page, 0, 4096) != hipSuccess) {
+    // (the fill goes through a private non-blocking stream: a context may be created while another host thread
+    //  captures a graph — execution lanes — and a legacy-stream hipMemset would try to join that capture)
+    hipStream_t s0 = nullptr;
+    bool ok = hipMalloc(&c->zero_page, 4096) == hipSuccess && hipStreamCreateWithFlags(&s0, hipStreamNonBlocking) == hipSuccess &&
+              hipMemsetAsync(c->zero_page, 0, 4096, s0) == hipSuccess && hipStreamSynchronize(s0) == hipSuccess;
+    if (s0) (void)hipStreamDestroy(s0);
+    (void)hipSetDevice(cur);
+    if (!ok) {
+      (void)hipGetLastError();
+      if (c->zero_page) (void)hipFree(c->zero_page);
       delete c;
       return UPK_EHIP;
     }
-    (void)hipSetDevice(cur);
   }
   c->cfg_override = -1;
   c->splitk_override = 0;

@@ -9,7 +9,7 @@ from . import _lib as L
 from . import knobs as K
 from ._check import require
 from .packing import PW, Packer, _rup, head_pad
-from .tuning import TUNE_CACHE
+from .tuning import TUNE_CACHE, TUNE_CACHE_LANES
 
 
 class Act:
@@ -82,19 +82,31 @@ class Emitter:
         """Pins each conv launch to the (tile config, split-K) stored in the tuning cache;
         with tune_missing=True unknown shapes are timed on the device first
         (upk_conv_autotune) and added to the cache.  Returns (#hits, #tuned, #missing)."""
-        cache = TUNE_CACHE if cache is None else cache
+        overlay = None
+        if cache is None:
+            cache = TUNE_CACHE
+            if L.concurrency() > 1 and os.environ.get("UPGPT_LANES_TUNING", "1") == "1":
+                overlay = TUNE_CACHE_LANES  # (several batches in flight: the throughput-tuned choices come first)
+                overlay.bind(self.lib)
         cache.bind(self.lib)
-        hits = tuned = missing = 0
-        for d, key in self.convs:
-            ent = cache.get(key)
+
+        def lookup(c, key):
+            ent = c.get(key)
             if ent is None and not tune_missing and key.endswith("_gs"):
-                ent = cache.get(key[:-3])  # (statistics by-product armed on a shape that was tuned without it)
+                ent = c.get(key[:-3])  # (statistics by-product armed on a shape that was tuned without it)
             if ent is None and not tune_missing and not key.endswith("_gs"):
-                ent = cache.get(key + "_gs")  # (tuned with the statistics by-product armed; the choice is valid without)
+                ent = c.get(key + "_gs")  # (tuned with the statistics by-product armed; the choice is valid without)
             if ent is None and not tune_missing and key.endswith("_lnr"):
-                ent = cache.get(key[:-4])  # (tuned as a plain GEMM; usable only if that choice does not split K)
+                ent = c.get(key[:-4])  # (tuned as a plain GEMM; usable only if that choice does not split K)
                 if ent is not None and int(ent[1]) != 1 and not self._is_as(int(ent[0])):
                     ent = None
+            return ent
+
+        hits = tuned = missing = 0
+        for d, key in self.convs:
+            ent = lookup(overlay, key) if overlay is not None else None
+            if ent is None:
+                ent = lookup(cache, key)
             if ent is None and tune_missing:
                 cfg, sk, best_us, dflt_us = self.ctx.conv_autotune(d, reps or int(os.environ.get("UPGPT_TUNE_REPS", "5")))
                 ent = cache.put(key, cfg, sk, best_us, dflt_us)

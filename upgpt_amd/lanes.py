@@ -11,7 +11,9 @@ the serial path's (tests/test_lanes_gpu.py).  This is the serving shape of the p
 batch each — not a larger batch: the batch of a UNetModel.forward does not change.
 """
 import contextlib
+import os
 import threading
+import time
 
 import torch
 
@@ -36,9 +38,63 @@ class LanePool:
         self.n = int(n)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.gpu = self.device.type == "cuda"
-        # lane 0 runs on the caller's stream, so that a one-lane pool is exactly the serial path
-        self.streams = [None] + [torch.cuda.Stream(device=self.device) if self.gpu else None for _ in range(self.n - 1)]
+        if self.gpu and self.n > 1:
+            from ._lib import concurrency, set_concurrency
+            set_concurrency(max(concurrency(), self.n))  # (plans built from now on are tuned for a shared chip)
+            from ._lib import get_context
+            for i in range(self.n):  # every lane's upk_ctx + workspace exists before the first thread starts
+                get_context(self.device, lane=i)
+        self.queue_probe = "n/a"
+        # a one-lane pool is exactly the serial path (caller's stream); with more lanes every lane has a stream of its own
+        # (UPGPT_LANE0_MAIN=1: lane 0 on the caller's stream instead)
+        self.lane0_main = os.environ.get("UPGPT_LANE0_MAIN", "0") == "1"
+        k = self.n - 1 if self.lane0_main else self.n
+        self.streams = [None] * self.n if not self.gpu or self.n == 1 else (
+            ([None] if self.lane0_main else []) + self._distinct_queue_streams(k, with_main=self.lane0_main))
         self._xstream = torch.cuda.Stream(device=self.device) if self.gpu and self.n > 1 else None
+
+    # ---- stream -> hardware queue placement
+    def _overlap(self, sa, sb, cycles):
+        """Do kernels on streams sa and sb run at the same time?  One spinning single-thread kernel on each: two streams
+        that the HIP runtime mapped to ONE hardware queue run them back to back."""
+        def run(streams):
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            for s in streams:
+                with torch.cuda.stream(s):
+                    torch.cuda._sleep(cycles)
+            torch.cuda.synchronize(self.device)
+            return time.perf_counter() - t0
+        one = min(run([sa]) for _ in range(3))
+        two = min(run([sa, sb]) for _ in range(3))
+        return two < 1.5 * one, one
+
+    def _distinct_queue_streams(self, k, candidates=12, with_main=True):
+        """k streams that share a hardware queue neither with the caller's stream nor with each other.  The runtime
+        multiplexes its streams onto a few hardware queues (4 by default) in creation order; two lanes that land on one
+        queue take turns instead of overlapping (measured: 5.70 ms for two forwards against 4.25 ms on two queues,
+        scripts/stream_queues.py), so the pool measures instead of trusting the order.  Falls back to fresh streams when
+        the probe is unavailable or finds too few queues."""
+        with torch.cuda.device(self.device):
+            main = torch.cuda.current_stream(self.device)
+            cands = [torch.cuda.Stream(device=self.device) for _ in range(candidates)]
+            chosen = []
+            try:
+                cycles = 200000
+                ok, one = self._overlap(main, main, cycles)  # (calibration: the same stream never overlaps itself)
+                if ok or one < 2e-5:
+                    raise RuntimeError("spin probe does not resolve on this device")
+                for c in cands:
+                    if len(chosen) == k:
+                        break
+                    if all(self._overlap(o, c, cycles)[0] for o in ([main] if with_main else []) + chosen):
+                        chosen.append(c)
+            except Exception:
+                chosen = []
+            self.queue_probe = "measured" if len(chosen) == k else "unverified"
+            if len(chosen) < k:
+                chosen = (chosen + [c for c in cands if c not in chosen])[:k]
+            return chosen
 
     def _lane_steps(self, i, stream, fn, K, slots, cond, errors):
         try:
@@ -68,10 +124,11 @@ class LanePool:
             return outs
         main = torch.cuda.current_stream(self.device) if self.gpu else None
         slots, errors, cond = [None] * K, [], threading.Condition()
-        streams = [main] + self.streams[1:]
+        streams = [main if s is None else s for s in self.streams]
         if self.gpu:
-            for s in streams[1:]:
-                s.wait_stream(main)  # (inputs prepared on the caller's stream are visible to every lane)
+            for s in streams:
+                if s is not main:
+                    s.wait_stream(main)  # (inputs prepared on the caller's stream are visible to every lane)
         threads = [threading.Thread(target=self._lane_steps, args=(i, streams[i], fn, K, slots, cond, errors), daemon=True)
                    for i in range(self.n)]
         for t in threads:
@@ -106,8 +163,9 @@ class LanePool:
             for t in threads:
                 t.join()
             if self.gpu:
-                for s in streams[1:] + ([xs] if xs is not None else []):
-                    main.wait_stream(s)
+                for s in streams + ([xs] if xs is not None else []):
+                    if s is not main:
+                        main.wait_stream(s)
         if errors:
             raise errors[0]
         return outs

@@ -76,3 +76,9 @@ class TuneCache:
 
 
 TUNE_CACHE = TuneCache(os.environ.get("UPGPT_TUNE_FILE") or None)
+# Overlay for plans built while several batches are in flight on the device (execution lanes, lanes.py): the choices of
+# an in-situ pass whose objective is the time per forward of THREE concurrent forwards (scripts/tune_insitu.py with
+# INSITU_LANES=3) — with the chip shared, a launch is priced by the CU time it takes, not by its latency alone.  Only
+# the shapes that pass changed; everything else falls through to TUNE_CACHE.
+TUNE_CACHE_LANES = TuneCache(os.environ.get("UPGPT_TUNE_FILE_LANES") or
+                             os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950_lanes.json"))

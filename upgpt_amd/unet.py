@@ -31,7 +31,7 @@ class UNetModel(ParamTree):
         self.predict_codebook_ids = False
         self.add_params(a.param_shapes())
         self._packed = {}     # tag -> (fingerprint, PackedUNet)
-        self._plans = {}      # (tag, B, H, W, n_ctx, rows, mode, lane) -> UNetPlan
+        self._plans = {}      # (tag, B, H, W, n_ctx, rows, mode, several batches in flight, lane) -> UNetPlan
         self._weight_override = None  # (tag, callable name -> tensor): EMA weights without copying
 
     # ---- engine plumbing
@@ -80,10 +80,10 @@ class UNetModel(ParamTree):
             return self._plan_locked(B, H, W, n_ctx, rows, mode)
 
     def _plan_locked(self, B, H, W, n_ctx, rows, mode):
-        from ._lib import current_lane
+        from ._lib import concurrency, current_lane
         from .engine import UNetPlan
         ctx, tag, pk = self.packed()  # (ctx = the calling thread's lane: own workspace, own buffers; weights shared)
-        key = (tag, B, H, W, n_ctx, rows, mode, current_lane())
+        key = (tag, B, H, W, n_ctx, rows, mode, concurrency() > 1, current_lane())
         pl = self._plans.get(key)
         if pl is None:
             if len(self._plans) >= 16:  # bound device memory held by stale shapes (a shape counts once per lane)
