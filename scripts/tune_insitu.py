@@ -46,6 +46,11 @@ pl.prep.run()
 st = SamplerState(pl, CH); st.x.copy_(inp["x_T"].cuda()); st.coefs.fill_(0.5)
 ctx = pl.ctx
 lane_plans, lane_states, lane_streams = [pl], [st], [torch.cuda.current_stream()]
+if LANES > 1:
+    from upgpt_amd.lanes import LanePool
+    _pool = LanePool(LANES)  # (its streams are probed to sit on distinct hardware queues)
+    print("lane streams on distinct hardware queues:", _pool.queue_probe, flush=True)
+    lane_streams = list(_pool.streams)
 for i in range(1, LANES):
     with upgpt_amd.lane(i):
         p2 = unet.plan(BATCH, H, W, NTOK, 50, "sampler")
@@ -53,7 +58,7 @@ for i in range(1, LANES):
         p2.load_context(inp["c_crossattn"].cuda()); p2.t_rows.copy_(torch.arange(981, 0, -20, dtype=torch.float32)[:50])
         p2.prep.run()
         s2 = SamplerState(p2, CH); s2.x.copy_(inp["x_T"].cuda()); s2.coefs.fill_(0.5)
-    lane_plans.append(p2); lane_states.append(s2); lane_streams.append(torch.cuda.Stream())
+    lane_plans.append(p2); lane_states.append(s2)
 torch.cuda.synchronize()
 ncfg = ctx.lib.upk_conv_num_configs()
 names = [ctx.lib.upk_conv_config_name(i).decode() for i in range(ncfg)]
@@ -146,9 +151,12 @@ def share(key):
 
 changed = {}
 cur = base
-for key in sorted(groups, key=share, reverse=True):
+MAXSHAPES = int(os.environ.get("INSITU_MAXSHAPES", "0"))  # only the N shapes with the largest time share
+for rank_, key in enumerate(sorted(groups, key=share, reverse=True)):
     if KEYSUB and KEYSUB not in key:
         continue
+    if MAXSHAPES and rank_ >= MAXSHAPES:
+        break
     ds = groups[key]
     d0 = ds[0]
     start = (d0.tune_cfg - 1, d0.tune_splitk) if d0.tune_cfg > 0 else None

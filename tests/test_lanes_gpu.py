@@ -41,27 +41,29 @@ def job(model, B, hw, S, seed, eta=0.0):
 
 
 @pytest.mark.parametrize("kind,B,hw,S,eta,lanes", [("tiny", 3, (32, 24), 10, 0.0, 2), ("tiny", 2, (32, 24), 10, 1.0, 3),
-                                                   ("bbox", 8, (32, 32), 50, 0.0, 3)])
+                                                   ("bbox", 8, (32, 32), 50, 0.0, 4)])
 def test_batches_in_flight_are_bit_identical_to_one_at_a_time(kind, B, hw, S, eta, lanes):
     model = get_model(kind)
     K = 2 * lanes
     jobs = [job(model, B, hw, S, seed=40 + k, eta=eta) for k in range(K)]
     pool = LanePool(lanes)  # (from here on plans take the launch choices tuned for a shared chip: serial run included)
-    serial = [j() for j in jobs]  # lane 0, one batch at a time
-    torch.cuda.synchronize()
     seen = []
 
     def step(k):
         seen.append((k, L.current_lane()))
         return jobs[k]()
 
+    serial = [step(k) for k in range(K)]
+    torch.cuda.synchronize()
     for rep in range(2):  # (first pass builds the other lanes' plans and graphs, second replays them)
         outs = pool.run(step, K)
         torch.cuda.synchronize()
         for k, ((z0, im0), (z1, im1)) in enumerate(zip(serial, outs)):
             assert torch.equal(z0, z1), "latents of step %d (lane %d) differ from the serial run" % (k, k % lanes)
             assert torch.equal(im0, im1), "images of step %d (lane %d) differ from the serial run" % (k, k % lanes)
-    assert sorted(seen) == sorted([(k, k % lanes) for k in range(K)] * 2)
+    assert sorted(seen) == sorted([(k, 0) for k in range(K)] + [(k, k % lanes) for k in range(K)] * 2)
+    assert pool.queue_probe == "measured", "the lanes' streams were not verified to sit on distinct hardware queues"
+    assert len({s.cuda_stream for s in pool.streams}) == lanes
     unet = model.model.diffusion_model
     assert {k[-1] for k in unet._plans} >= set(range(lanes))  # every lane has plans of its own ...
     ctxs = {id(p.ctx) for k, p in unet._plans.items()}

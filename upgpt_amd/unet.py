@@ -86,8 +86,9 @@ class UNetModel(ParamTree):
         key = (tag, B, H, W, n_ctx, rows, mode, concurrency() > 1, current_lane())
         pl = self._plans.get(key)
         if pl is None:
-            if len(self._plans) >= 16:  # bound device memory held by stale shapes (a shape counts once per lane)
-                self._plans.pop(next(iter(self._plans))).close()
+            mine = [k for k in self._plans if k[-1] == key[-1]]
+            if len(mine) >= 8:  # bound device memory held by stale shapes — per lane: another lane's plans may be executing
+                self._plans.pop(mine[0]).close()
             with torch.cuda.device(ctx.device):
                 pl = UNetPlan(ctx, pk, B, H, W, n_ctx, rows, mode)
                 pl.apply_tuning(tune_missing=os.environ.get("UPGPT_AUTOTUNE", "0") == "1")

@@ -100,8 +100,9 @@ class AutoencoderKL(ParamTree):
         from ._lib import current_lane
         key = (B, h, w, float(scale_factor), current_lane())
         if key not in self._plans:
-            if len(self._plans) >= 8:
-                self._plans.pop(next(iter(self._plans)))
+            mine = [k for k in self._plans if k[-1] == key[-1]]
+            if len(mine) >= 4:  # (per lane: another lane's plans may be executing)
+                self._plans.pop(mine[0])
             with torch.cuda.device(p.device):
                 self._plans[key] = VAEDecodePlan(ctx, self._packed[1], B, h, w, scale_factor)
                 self._plans[key].apply_tuning(tune_missing=os.environ.get("UPGPT_AUTOTUNE", "0") == "1")
@@ -138,8 +139,9 @@ class AutoencoderKL(ParamTree):
         from ._lib import current_lane
         key = (B, H, W, current_lane())
         if key not in self._enc_plans:
-            if len(self._enc_plans) >= 8:
-                self._enc_plans.pop(next(iter(self._enc_plans)))
+            mine = [k for k in self._enc_plans if k[-1] == key[-1]]
+            if len(mine) >= 4:
+                self._enc_plans.pop(mine[0])
             with torch.cuda.device(p.device):
                 self._enc_plans[key] = VAEEncodePlan(ctx, self._packed_enc[1], B, H, W)
                 self._enc_plans[key].apply_tuning(tune_missing=os.environ.get("UPGPT_AUTOTUNE", "0") == "1")
