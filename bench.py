@@ -538,8 +538,8 @@ def upscale_secondary(ddim_steps, dev, batch=4, hw=(64, 64)):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--latent", default="32x32", help="HxW of the latent (32x32 = 256x256 px)")
