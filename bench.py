@@ -469,7 +469,7 @@ def cpu_baseline(hw, ddim_steps, batch):
             "config0_single_sample_10step_s": t_loop + t_dec}
 
 
-def encoders_secondary(model, wl, dev):
+def encoders_secondary(model, wl, dev, pool=None):
     """BASELINE configs[2] with the conditioning computed on the device: token ids [B, 77] -> CLIP text tower, style
     crops [B, 9, 3, 224, 224] -> CLIP ViT-L/14 image tower, SMPL [B, 1, 85] -> LinearProject, concatenated to the
     [B, 87, 768] context (ddpm.py:734-739), then the main workload (50-step DDIM + decode)."""
@@ -489,25 +489,37 @@ def encoders_secondary(model, wl, dev):
     smpl = (0.5 * torch.randn(B, 1, 85, generator=g)).cuda()
     pose = model.extra_cond_models[1]
 
-    def run():
+    from upgpt_amd.ddim import DDIMSampler
+    n = pool.n if pool is not None else 1
+    samplers = [DDIMSampler(model) for _ in range(n)]
+
+    def run(k=0):
         ctx = torch.cat([txt.encode_tokens(ids), img(crops), pose(smpl)], 1)
         with model.ema_scope():
-            z, _ = wl.sampler.sample(wl.S, B, (4,) + tuple(wl.hw), {"c_crossattn": ctx, "c_concat": wl.cond["c_concat"]},
-                                     eta=0.0, x_T=wl.x_T, verbose=False, log_every_t=10 ** 6)
+            z, _ = samplers[k % n].sample(wl.S, B, (4,) + tuple(wl.hw), {"c_crossattn": ctx, "c_concat": wl.cond["c_concat"]},
+                                          eta=0.0, x_T=wl.x_T, verbose=False, log_every_t=10 ** 6)
         return model.decode_first_stage(z)
 
     def enc_only():
         return torch.cat([txt.encode_tokens(ids), img(crops), pose(smpl)], 1)
 
+    note = "token ids / pre-processed crops in (tokenizer and crop pre-processing stay on the host)"
+    if n > 1:
+        with contextlib.redirect_stdout(io.StringIO()):
+            timed_lanes(pool, run, n, dev)
+            dt, out = timed_lanes(pool, run, 2 * n, dev)
+        te, _ = timed(enc_only, 3, dev)
+        assert torch.isfinite(out).all()
+        return {"value": B * 2 * n / dt, "unit": "images/s", "ms_per_step": dt / (2 * n) * 1e3, "encoders_ms": te / 3 * 1e3,
+                "batches_in_flight_per_gpu": n, "note": note}
     quiet(run)
     dt, out = timed(lambda: quiet(run), 2, dev)
     te, _ = timed(enc_only, 3, dev)
     assert torch.isfinite(out).all()
-    return {"value": B * 2 / dt, "unit": "images/s", "ms_per_step": dt / 2 * 1e3, "encoders_ms": te / 3 * 1e3,
-            "note": "token ids / pre-processed crops in (tokenizer and crop pre-processing stay on the host)"}
+    return {"value": B * 2 / dt, "unit": "images/s", "ms_per_step": dt / 2 * 1e3, "encoders_ms": te / 3 * 1e3, "note": note}
 
 
-def upscale_secondary(ddim_steps, dev, batch=4, hw=(64, 64)):
+def upscale_secondary(ddim_steps, dev, batch=4, hw=(64, 64), pool=None):
     """BASELINE configs[4] as worded there: the upscale model (models/upgpt/upscale/config.yaml) at bs=4 on a 64x64
     latent, 50-step DDIM; UNet sampling loop only (its kl-f4 first stage is outside the path)."""
     import upgpt_amd
@@ -519,19 +531,28 @@ def upscale_secondary(ddim_steps, dev, batch=4, hw=(64, 64)):
     inp = synth.synth_inputs(batch, hw, 3, 86, 768, seed=0, concat_channels=3)
     cond = {"c_crossattn": inp["c_crossattn"].cuda(), "c_concat": [inp["c_concat"].cuda()]}
     x_T = inp["x_T"].cuda()
-    sampler = DDIMSampler(m)
+    n = pool.n if pool is not None else 1
+    samplers = [DDIMSampler(m) for _ in range(n)]
 
-    def run():
-        z, _ = sampler.sample(ddim_steps, batch, (3,) + tuple(hw), cond, eta=0.0, x_T=x_T, verbose=False,
-                              log_every_t=10 ** 6)
+    def run(k=0):
+        z, _ = samplers[k % n].sample(ddim_steps, batch, (3,) + tuple(hw), cond, eta=0.0, x_T=x_T, verbose=False,
+                                      log_every_t=10 ** 6)
         return z
 
-    quiet(run)
-    dt, z = timed(lambda: quiet(run), 2, dev)
-    assert torch.isfinite(z).all()
     gf = arch.UNetArch(**synth.UPSCALE_UNET).flops(batch, hw[0], hw[1], 86) / 1e9
-    fwd_ms = dt / 2 / ddim_steps * 1e3
-    return {"value": batch * 2 / dt, "unit": "images/s (UNet DDIM loop, no decode)", "ms_per_unet_step": fwd_ms,
+    if n > 1:
+        with contextlib.redirect_stdout(io.StringIO()):
+            timed_lanes(pool, run, n, dev)
+            dt, z = timed_lanes(pool, run, 2 * n, dev)
+        steps = 2 * n
+    else:
+        quiet(run)
+        dt, z = timed(lambda: quiet(run), 2, dev)
+        steps = 2
+    assert torch.isfinite(z).all()
+    fwd_ms = dt / steps / ddim_steps * 1e3
+    return {"value": batch * steps / dt, "unit": "images/s (UNet DDIM loop, no decode)", "ms_per_unet_step": fwd_ms,
+            "batches_in_flight_per_gpu": n,
             "algorithmic_gflop_per_fwd": gf, "mfma_util": gf * 1e9 / (fwd_ms * 1e-3) / (PEAK_MFMA_F16_TFLOPS * 1e12)}
 
 
@@ -713,24 +734,33 @@ def main():
                     "unet_fwd_ms_graph": unet_forward_ms(model, wl2),
                     "algorithmic_gflop_per_fwd": a.flops(args.batch, 32, 24, 87) / 1e9}
             result["config_true_256x192"] = ser2 if cfg_true_lanes is None else dict(cfg_true_lanes, serial=ser2)
+        # the other BASELINE configurations, in the bench's own mode (lanes > 1: that many batches in flight)
+        sec_pool = pool if n_lanes > 1 else None
+        _L.set_concurrency(n_lanes)
         if args.cfg and world == 1:
             uc = {"c_crossattn": torch.zeros_like(wl.cond["c_crossattn"]), "c_concat": wl.cond["c_concat"]}
+            from upgpt_amd.ddim import DDIMSampler
+            cfg_samplers = [DDIMSampler(model) for _ in range(n_lanes)]
 
-            def run_cfg():
+            def run_cfg(k=0):
                 with model.ema_scope():
-                    z, _ = wl.sampler.sample(wl.S, wl.B, (4,) + tuple(wl.hw), wl.cond, eta=0.0, x_T=wl.x_T, verbose=False,
-                                             log_every_t=10 ** 6, unconditional_guidance_scale=args.cfg,
-                                             unconditional_conditioning=uc)
+                    z, _ = cfg_samplers[k % n_lanes].sample(wl.S, wl.B, (4,) + tuple(wl.hw), wl.cond, eta=0.0, x_T=wl.x_T,
+                                                            verbose=False, log_every_t=10 ** 6,
+                                                            unconditional_guidance_scale=args.cfg,
+                                                            unconditional_conditioning=uc)
                 return model.decode_first_stage(z)
 
-            quiet(run_cfg)
-            dtc, _ = timed(lambda: quiet(run_cfg), 2, dev)
-            result["config_cfg"] = {"value": args.batch * 2 / dtc, "unit": "images/s", "guidance_scale": args.cfg,
-                                    "ms_per_step": dtc / 2 * 1e3, "unet_rows": 2 * args.batch}
+            kc = 2 * n_lanes
+            with contextlib.redirect_stdout(io.StringIO()):
+                timed_lanes(pool, run_cfg, n_lanes, dev)
+                dtc, _ = timed_lanes(pool, run_cfg, kc, dev)
+            result["config_cfg"] = {"value": args.batch * kc / dtc, "unit": "images/s", "guidance_scale": args.cfg,
+                                    "ms_per_step": dtc / kc * 1e3, "unet_rows": 2 * args.batch,
+                                    "batches_in_flight_per_gpu": n_lanes}
         if args.encoders and world == 1:
-            result["config_full_cond_with_encoders"] = encoders_secondary(model, wl, dev)
+            result["config_full_cond_with_encoders"] = encoders_secondary(model, wl, dev, sec_pool)
         if args.upscale and world == 1:
-            result["config_upscale_bs4_64x64"] = upscale_secondary(args.ddim_steps, dev)
+            result["config_upscale_bs4_64x64"] = upscale_secondary(args.ddim_steps, dev, pool=sec_pool)
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(hw, args.ddim_steps, args.batch)
         print(json.dumps(result), flush=True)

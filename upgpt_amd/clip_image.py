@@ -141,18 +141,21 @@ class CLIPVisual(ParamTree):
         if p.device.type != "cuda":
             raise RuntimeError("upgpt_amd.CLIPVisual computes only through the HIP kernels on an MI355X: move it to 'cuda' "
                                "first. There is no CPU fallback.")
-        from ._lib import get_context
-        fp = weights_fingerprint(self)
-        if fp != self._fp:
-            self._plans, self._fp = {}, fp
-        N = int(images.shape[0])
-        plan = self._plans.get(N)
-        if plan is None:
-            if len(self._plans) >= 2:
-                self._plans.pop(next(iter(self._plans)))
-            params = dict(self.named_parameters())
-            with torch.cuda.device(p.device):
-                plan = self._plans[N] = _VisualPlan(get_context(p.device), self.config, lambda n: params[n].data, N)
+        from ._lib import PLAN_LOCK, current_lane, get_context
+        with PLAN_LOCK:  # (execution lanes: a plan — buffers and packed weights — per (crop count, lane))
+            fp = weights_fingerprint(self)
+            if fp != self._fp:
+                self._plans, self._fp = {}, fp
+            N = int(images.shape[0])
+            key = (N, current_lane())
+            plan = self._plans.get(key)
+            if plan is None:
+                mine = [k for k in self._plans if k[1] == key[1]]
+                if len(mine) >= 2:
+                    self._plans.pop(mine[0])
+                params = dict(self.named_parameters())
+                with torch.cuda.device(p.device):
+                    plan = self._plans[key] = _VisualPlan(get_context(p.device), self.config, lambda n: params[n].data, N)
         with torch.cuda.device(p.device):
             return plan.run(images)
 

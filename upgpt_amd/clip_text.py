@@ -183,19 +183,22 @@ class _TextTower(ParamTree):
         if p.device.type != "cuda":
             raise RuntimeError("upgpt_amd.%s computes only through the HIP kernels on an MI355X: move it to 'cuda' first. "
                                "There is no CPU fallback." % type(self).__name__)
-        from ._lib import get_context
-        fp = weights_fingerprint(self)
-        if fp != self._fp:
-            self._plans, self._fp = {}, fp
-        B = int(input_ids.shape[0])
-        plan = self._plans.get(B)
-        if plan is None:
-            if len(self._plans) >= 4:
-                self._plans.pop(next(iter(self._plans)))
-            params = dict(self.named_parameters())
-            with torch.cuda.device(p.device):
-                plan = self._plans[B] = _TextPlan(get_context(p.device), self.config, lambda n: params[n].data, B,
-                                                  names=self.NAMES)
+        from ._lib import PLAN_LOCK, current_lane, get_context
+        with PLAN_LOCK:  # (execution lanes: a plan — buffers and packed weights — per (batch, lane))
+            fp = weights_fingerprint(self)
+            if fp != self._fp:
+                self._plans, self._fp = {}, fp
+            B = int(input_ids.shape[0])
+            key = (B, current_lane())
+            plan = self._plans.get(key)
+            if plan is None:
+                mine = [k for k in self._plans if k[1] == key[1]]
+                if len(mine) >= 4:
+                    self._plans.pop(mine[0])
+                params = dict(self.named_parameters())
+                with torch.cuda.device(p.device):
+                    plan = self._plans[key] = _TextPlan(get_context(p.device), self.config, lambda n: params[n].data, B,
+                                                        names=self.NAMES)
         with torch.cuda.device(p.device):
             return plan.run(input_ids)
 
