@@ -620,8 +620,11 @@ def main():
 
     with contextlib.redirect_stdout(io.StringIO()):  # (the sampler prints like the reference; stdout carries the JSON line)
         # every lane builds its plans / graphs on its first step: warm each lane at least once, W steps in total at least
-        timed_lanes(pool, step_k, max(args.warmup, n_lanes), dev, after=gather_k)
+        # (and twice per lane: the second step of a lane still draws new blocks from the caching allocator, and a
+        #  hipMalloc inside the timed region would stall every lane)
+        timed_lanes(pool, step_k, max(args.warmup, 2 * n_lanes), dev, after=gather_k)
         dt, out = timed_lanes(pool, step_k, args.steps, dev, after=gather_k)
+    lane_ms = pool.lane_step_ms() if n_lanes > 1 else None
     dt = D.max_over_ranks(dt, dev)
     assert out.shape[0] == args.batch * world and torch.isfinite(out).all()
     images = args.batch * world * args.steps
@@ -643,7 +646,8 @@ def main():
     }
     if serial is not None:
         result["serial"] = serial
-        result["step_latency_ms"] = dt / args.steps * 1e3 * n_lanes  # (a batch's own time in flight, approx.)
+        # a batch's own time in flight (device time between the ends of consecutive steps of a lane), per lane
+        result["step_latency_ms"] = [round(sum(v) / max(1, len(v)), 2) for v in lane_ms]
     if rank == 0:
         a = arch.UNetArch(**synth.BBOX_UNET)
         flops_fwd = a.flops(args.batch, hw[0], hw[1], 87)

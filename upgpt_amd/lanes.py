@@ -99,12 +99,18 @@ class LanePool:
     def _lane_steps(self, i, stream, fn, K, slots, cond, errors):
         try:
             with (torch.cuda.device(self.device) if self.gpu else contextlib.nullcontext()), lane(i, stream):
+                prev = None
+                if self.gpu:
+                    prev = torch.cuda.Event(enable_timing=True)
+                    prev.record(torch.cuda.current_stream(self.device))
                 for k in range(i, K, self.n):
                     out = fn(k)
                     ev = None
                     if self.gpu:
-                        ev = torch.cuda.Event()
+                        ev = torch.cuda.Event(enable_timing=True)
                         ev.record(torch.cuda.current_stream(self.device))
+                        self._spans.append((i, k, prev, ev))  # (device time of step k on its lane: lane_step_ms())
+                        prev = ev
                     with cond:
                         slots[k] = (out, ev)
                         cond.notify_all()
@@ -112,6 +118,15 @@ class LanePool:
             with cond:
                 errors.append(e)
                 cond.notify_all()
+
+    def lane_step_ms(self):
+        """Device time of every step of the last run() on its lane, per lane: [[ms, ...] for each lane] (synchronises)."""
+        out = [[] for _ in range(self.n)]
+        if self.gpu:
+            torch.cuda.synchronize(self.device)
+            for i, k, e0, e1 in sorted(getattr(self, "_spans", []), key=lambda t: t[1]):
+                out[i].append(e0.elapsed_time(e1))
+        return out
 
     def run(self, fn, K, after=None):
         """-> list of the K results (of `after` when given).  Device work may still be in flight when run() returns; the
@@ -124,6 +139,7 @@ class LanePool:
             return outs
         main = torch.cuda.current_stream(self.device) if self.gpu else None
         slots, errors, cond = [None] * K, [], threading.Condition()
+        self._spans = []
         streams = [main if s is None else s for s in self.streams]
         if self.gpu:
             for s in streams:
