@@ -103,11 +103,12 @@ def timed_lanes(pool, step_fn, n, dev, after=None):
     lane run in order, steps of different lanes overlap on the device).  `after(k, images)` runs in step order on
     every rank (the all-gather).  -> (seconds, result of the last step)."""
     from upgpt_amd import dist as D
+    sync = (lambda: torch.cuda.synchronize(dev)) if torch.device(dev).type == "cuda" else (lambda: None)
     D.barrier()
-    torch.cuda.synchronize(dev)
+    sync()
     t0 = time.perf_counter()
     outs = pool.run(step_fn, n, after=after)
-    torch.cuda.synchronize(dev)
+    sync()
     D.barrier()
     return time.perf_counter() - t0, outs[-1]
 
@@ -191,7 +192,7 @@ def kernel_class_profile(model, wl, reps=20):
     return out, body.igemm_flops, body.attn_flops, n_kernels, full
 
 
-def lanes_class_profile(model, pool, wl, reps=8):
+def lanes_class_profile(model, pool, wl, reps=8, ncand=6):
     """What a kernel class costs with `pool.n` forwards in flight — the configuration the timed region runs: the captured
     UNet forward of every lane (the lanes' own plans, streams on distinct hardware queues) replayed concurrently, in full and
     without the class in every lane; the wall time per forward and its difference are CHIP time: with the device shared, a
@@ -206,13 +207,13 @@ def lanes_class_profile(model, pool, wl, reps=8):
                 plans.append(unet.plan(wl.B, wl.hw[0], wl.hw[1], 87, wl.S, "sampler"))
             streams.append(pool.streams[i] if pool.streams[i] is not None else torch.cuda.current_stream())
 
-        def replay(skip=()):
+        def replay(skip=(), skip_idx=()):
             gs = []
             for p, s in zip(plans, streams):
                 ctx = p.ctx
                 with torch.cuda.stream(s):
                     ctx._chk(ctx.lib.upk_graph_begin(ctx.h, s.cuda_stream))
-                    p.body.run(s.cuda_stream, skip=skip)
+                    p.body.run(s.cuda_stream, skip=skip, skip_idx=skip_idx)
                     g = C.c_void_p()
                     ctx._chk(ctx.lib.upk_graph_end(ctx.h, s.cuda_stream, C.byref(g)))
                 gs.append(g)
@@ -236,10 +237,42 @@ def lanes_class_profile(model, pool, wl, reps=8):
         out = {}
         for k, classes in (("igemm", ("igemm_k1", "igemm_k3")), ("attention", ("attention",)), ("groupnorm", ("groupnorm",))):
             out[k] = sorted(full - replay(classes) for _ in range(2))[0]
+        # the (kernel instantiation, grid) with the largest chip time in this configuration — the lanes' plans carry the
+        # launch choices tuned for a shared chip, so the groups are not those of the single-forward figure
+        body, ctx = plans[0].body, plans[0].ctx
+
+        def kernel_key(i):
+            d, lab = body.meta[i], body.labels[i]
+            if d is None or not d.tune_cfg:
+                return lab
+            up = 2 if d.flags & 0x10 else 1
+            M = d.batch * ((d.in_h * up + d.stride - 1) // d.stride) * ((d.in_w * up + d.stride - 1) // d.stride)
+            return "%s%s k%d M%d N%d z%d" % (ctx.lib.upk_conv_config_name(d.tune_cfg - 1).decode(), "+app" if (d.c3 or d.c4) else "",
+                                            d.ksize, M, d.n_pad, max(1, d.tune_splitk))
+
+        groups = {}
+        for i, c in enumerate(body.cls):
+            if c.startswith("igemm") or c == "attention":
+                groups.setdefault(kernel_key(i), []).append(i)
+        exe = lambda i: body.flops[i] * 4.0 / 9.0 if body.labels[i].endswith("_ph") else float(body.flops[i])
+        est = lambda idx: sum(6e-6 + exe(i) / 0.4e15 for i in idx)
+        best = None
+        for key, idx in sorted(groups.items(), key=lambda kv: -est(kv[1]))[:ncand]:
+            ms = sorted(full - replay(skip_idx=frozenset(idx)) for _ in range(2))[0]
+            if best is None or ms > best[0]:
+                best = (ms, key, idx)
+        ms, key, idx = best
+        fl = sum(exe(i) for i in idx)
+        dom = {"label": key, "shapes": sorted(set(body.labels[i] for i in idx)), "launches_per_fwd": len(idx),
+               "chip_ms_per_fwd": ms, "chip_us_per_launch": ms * 1e3 / len(idx), "share_of_forward_in_flight": ms / full,
+               "method": "as class_ms_per_fwd_in_flight, for one (kernel instantiation, grid) group: the largest of the %d groups "
+                         "a static estimate ranks highest" % ncand}
+        if fl:
+            dom.update({"flops_per_fwd": fl, "achieved": fl / (ms * 1e-3) / 1e12, "frac": fl / (ms * 1e-3) / 1e12 / PEAK_MFMA_F16_TFLOPS})
         for p in plans:
             p.prep.run()  # the ablated replays left garbage in the activations
         torch.cuda.synchronize()
-    return full, out
+    return full, out, dom
 
 
 def top_kernel_roofline(model, wl, reps=40):
@@ -702,7 +735,7 @@ def main():
         }
         if lanes_prof is not None:
             # the timed configuration: the class's chip time per forward with n_lanes forwards in flight
-            fwd_l, cls_l = lanes_prof
+            fwd_l, cls_l, dom_l = lanes_prof
             ser = {k: result["roofline"][k] for k in ("achieved", "frac", "avg_launch_us", "avg_kernel_us", "frac_layer", "method")}
             ach_l = ig_flops / (cls_l["igemm"] * 1e-3) / 1e12
             result["roofline"].update({
@@ -715,7 +748,7 @@ def main():
                           "forward with the chip to itself (graph-replay difference, HIP events), as in rounds 1-4; "
                           "top_kernel / dominant_kernel / l2_* are single-forward figures as well" % n_lanes,
                 "forwards_in_flight": n_lanes, "fwd_ms_per_forward_in_flight": fwd_l,
-                "class_ms_per_fwd_in_flight": cls_l, "serial": ser})
+                "class_ms_per_fwd_in_flight": cls_l, "dominant_kernel_in_flight": dom_l, "serial": ser})
         dk = result["roofline"]["dominant_kernel"]
         if dom_l2 and dk and dk.get("us_per_launch_in_situ"):
             result["roofline"]["l2_bytes_per_launch"] = dom_l2["bytes_per_launch"]

@@ -122,3 +122,39 @@ def test_all_gather_from_the_after_hook_pairs_up_across_two_ranks():
         assert p.exitcode == 0
     for r in range(2):  # step k of every rank met step k of the other one
         assert got[r] == [[float(k)] * 2 + [float(100 + k)] * 2 for k in range(8)]
+
+
+def test_bench_timed_lanes_runs_exactly_n_steps_with_the_exchange_in_step_order():
+    """bench.py's timed region in lanes mode (host logic on a CPU pool): exactly n steps, step k on lane k % lanes, the
+    exchange hook once per step in step order, the last step's result handed back."""
+    import bench
+    pool = LanePool(4, "cpu")
+    ran, gathered = [], []
+    lock = threading.Lock()
+
+    def step(k):
+        with lock:
+            ran.append((k, L.current_lane()))
+        return torch.full((1,), float(k))
+
+    dt, out = bench.timed_lanes(pool, step, 10, "cpu", after=lambda k, img: gathered.append(k) or img + 0.5)
+    assert dt > 0 and float(out) == 9.5
+    assert sorted(ran) == [(k, k % 4) for k in range(10)] and gathered == list(range(10))
+
+
+def test_throughput_overlay_is_consulted_only_with_several_batches_in_flight():
+    """tuning.TUNE_CACHE_LANES: a well-formed overlay next to the base table, keys of the base table's form, and
+    _lib.concurrency() as the switch (set by a LanePool with more than one lane on a GPU; never by a CPU pool)."""
+    from upgpt_amd.tuning import TUNE_CACHE, TUNE_CACHE_LANES
+    assert TUNE_CACHE_LANES.path.endswith("tuned_gfx950_lanes.json") and len(TUNE_CACHE_LANES.d) >= 20
+    assert TUNE_CACHE_LANES.names == TUNE_CACHE.names or TUNE_CACHE_LANES.names is not None
+    for k, v in TUNE_CACHE_LANES.d.items():
+        assert k.startswith("M") and "_N" in k and len(v) == 4 and int(v[1]) >= 1
+    assert L.concurrency() == 1
+    LanePool(3, "cpu")
+    assert L.concurrency() == 1
+    L.set_concurrency(4)
+    try:
+        assert L.concurrency() == 4
+    finally:
+        L.set_concurrency(1)
