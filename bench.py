@@ -24,6 +24,9 @@ import time
 
 # multi-process GPU work (RCCL) on this host needs dmabuf IPC; harmless for N = 1
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# the execution lanes want one hardware queue each: 4 is the runtime's default and the most that run side by side
+# (profiles/r05_lanes_stream_queue_matrix.txt: with 8, some queue pairs time-slice at 2.5x the serial time)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 
 import torch  # noqa: E402
 
