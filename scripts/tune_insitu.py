@@ -149,8 +149,88 @@ def share(key):
     return (e[2] if e else 10.0) * len(groups[key])
 
 
+START_CHIP = LANES > 1 and os.environ.get("INSITU_START_CHIP", "0") == "1"
+# the choices the run starts with (what the written table is compared against)
+ORIG = {key: ((groups[key][0].tune_cfg - 1, groups[key][0].tune_splitk) if groups[key][0].tune_cfg > 0 else None) for key in groups}
+CHIP_RANK = {}  # key -> candidates ranked by chip time (START_CHIP)
+
+
+def chip_us(ds_lane, cfg, sk, R=6):
+    """CHIP time per launch of one shape in configuration (cfg, sk): R back-to-back launches captured per lane, the LANES
+    graphs replayed concurrently — what the launch costs when four chains of ITSELF share the chip (a launch that fills
+    every CU with one workgroup pays its full latency, one with fewer / lighter workgroups packs)."""
+    olds = [(d.tune_cfg, d.tune_splitk) for d in ds_lane]
+    gs = []
+    try:
+        for d in ds_lane:
+            d.tune_cfg, d.tune_splitk = cfg + 1, sk
+        for p, d, strm in zip(lane_plans, ds_lane, lane_streams):
+            with torch.cuda.stream(strm):
+                p.ctx._chk(p.lib.upk_graph_begin(p.hctx, strm.cuda_stream))
+                try:
+                    for _ in range(R):
+                        p.ctx.conv(d)
+                finally:
+                    g = C.c_void_p(); rc = p.lib.upk_graph_end(p.hctx, strm.cuda_stream, C.byref(g))
+                p.ctx._chk(rc)
+            gs.append(g)
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                for p, g, strm in zip(lane_plans, gs, lane_streams):
+                    p.ctx._chk(p.lib.upk_graph_launch(p.hctx, g, strm.cuda_stream))
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / (3 * R * len(gs)) * 1e6)
+        return best
+    finally:
+        for p, g in zip(lane_plans, gs):
+            p.ctx.graph_destroy(g)
+        for d, o in zip(ds_lane, olds):
+            d.tune_cfg, d.tune_splitk = o
+
+
+if START_CHIP:
+    # phase A: every shape to the configuration with the lowest chip time of its own (all at once: a coordinate descent
+    # from the latency-tuned table cannot leave it one shape at a time — a launch with few large tiles gains nothing while
+    # every other lane still fills the CUs with one-workgroup-per-CU launches)
+    moved = 0
+    for key in sorted(groups, key=share, reverse=True):
+        if KEYSUB and KEYSUB not in key:
+            continue
+        ds = groups[key]
+        per = len(ds) // LANES
+        ds_lane = [ds[i * per] for i in range(LANES)]
+        d0 = ds[0]
+        start = (d0.tune_cfg - 1, d0.tune_splitk) if d0.tune_cfg > 0 else None
+        sks = sorted({1, 2, 3, 4, 6, 8} | ({start[1]} if start else set()))
+        rank = []
+        for c in range(ncfg):
+            if names[c].startswith("as") and d0.ksize != 1:
+                continue
+            for s_ in sks:
+                if not feasible(d0, c, s_):
+                    continue
+                try:
+                    rank.append((chip_us(ds_lane, c, s_), (c, s_)))
+                except Exception:
+                    torch.cuda.synchronize()
+        rank.sort()
+        CHIP_RANK[key] = [cs for _, cs in rank[:TOPK]]
+        if rank and rank[0][1] != start:
+            t_start = [t for t, cs in rank if cs == start]
+            print("chip  %-46s %s %.2f us -> %s %.2f us" % (key, (names[start[0]], start[1]) if start else None,
+                                                           t_start[0] if t_start else float("nan"),
+                                                           (names[rank[0][1][0]], rank[0][1][1]), rank[0][0]), flush=True)
+            for d in ds:
+                d.tune_cfg, d.tune_splitk = rank[0][1][0] + 1, rank[0][1][1]
+            moved += 1
+    t_all = replay_ms()
+    print("phase A: %d shapes moved to their chip-time best: forward %.4f -> %.4f ms" % (moved, base, t_all), flush=True)
+
 changed = {}
-cur = base
+cur = replay_ms() if START_CHIP else base
 MAXSHAPES = int(os.environ.get("INSITU_MAXSHAPES", "0"))  # only the N shapes with the largest time share
 for rank_, key in enumerate(sorted(groups, key=share, reverse=True)):
     if KEYSUB and KEYSUB not in key:
@@ -175,6 +255,11 @@ for rank_, key in enumerate(sorted(groups, key=share, reverse=True)):
                  if feasible(d0, c, s)]
         if not cands:
             continue
+    elif START_CHIP and key in CHIP_RANK:
+        cands = list(CHIP_RANK[key])
+        for extra in (start, ORIG.get(key)):  # (the phase-A choice and the table's own: the descent may go back)
+            if extra and extra not in cands:
+                cands.append(extra)
     else:
         cands = [(c, s) for c in range(ncfg) for s in sks if feasible(d0, c, s)]
     # keep the candidates the single-launch tuner ranks near the top (plus the current choice)
@@ -229,6 +314,12 @@ ent = dict(TUNE_CACHE_LANES.d) if LANES > 1 else dict(TUNE_CACHE.d)
 for key, (start, best, t_old, t_new) in changed.items():
     old = ent.get(key) or ent.get(key[:-3]) or TUNE_CACHE.get(key) or [0, 1, 0.0, 0.0]
     ent[key] = [best[0], best[1], old[2], old[3]]
+if START_CHIP:  # every shape whose final choice differs from the one the run started with (phase A + descent)
+    for key, ds in groups.items():
+        fin = (ds[0].tune_cfg - 1, ds[0].tune_splitk) if ds[0].tune_cfg > 0 else None
+        if fin and fin != ORIG.get(key):
+            old = ent.get(key) or TUNE_CACHE.get(key) or [0, 1, 0.0, 0.0]
+            ent[key] = [fin[0], fin[1], old[2], old[3]]
 ent["__configs__"] = names  # (the indices refer to THIS library's configuration list: TuneCache.bind)
 json.dump(ent, open(out, "w"), indent=0, sort_keys=True)
 json.dump({k: [list(v[0]) if v[0] else None, list(v[1]), v[2], v[3]] for k, v in changed.items()},
