@@ -417,6 +417,27 @@ def set_concurrency(n):
     _concurrency = max(1, int(n))
 
 
+_HOST_IO_LOCK = threading.RLock()
+_HOST_IO_OFF = os.environ.get("UPGPT_HOST_IO_LOCK", "1") == "0"  # (dev: A/B of the lock's cost)
+
+
+@contextlib.contextmanager
+def host_io():
+    """Brackets (a) every graph capture and (b) the host sections of a lane that upload from pageable host memory
+    (schedule tables, token ids, x_T given on the host): with several lanes the runtime rejects such an upload issued
+    while ANOTHER thread captures ("operation not permitted when stream is capturing", also in thread-local capture
+    mode), so the two never overlap.  The lane's own stream is drained BEFORE the lock is taken — a blocking upload waits
+    for the stream's earlier work (the lane's previous batch, hundreds of ms in flight) and must not do that inside the
+    lock.  A no-op with one batch in flight: the serial path is unchanged."""
+    if _concurrency <= 1 or _HOST_IO_OFF:
+        yield
+        return
+    if torch.cuda.is_available():
+        torch.cuda.current_stream().synchronize()
+    with _HOST_IO_LOCK:
+        yield
+
+
 def current_lane():
     """Index of the execution lane of the calling thread (0 unless inside `lane(i)`)."""
     return getattr(_lane, "i", 0)

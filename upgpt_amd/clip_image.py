@@ -141,7 +141,7 @@ class CLIPVisual(ParamTree):
         if p.device.type != "cuda":
             raise RuntimeError("upgpt_amd.CLIPVisual computes only through the HIP kernels on an MI355X: move it to 'cuda' "
                                "first. There is no CPU fallback.")
-        from ._lib import PLAN_LOCK, current_lane, get_context
+        from ._lib import PLAN_LOCK, current_lane, get_context, host_io
         with PLAN_LOCK:  # (execution lanes: a plan — buffers and packed weights — per (crop count, lane))
             fp = weights_fingerprint(self)
             if fp != self._fp:
@@ -154,9 +154,10 @@ class CLIPVisual(ParamTree):
                 if len(mine) >= 2:
                     self._plans.pop(mine[0])
                 params = dict(self.named_parameters())
-                with torch.cuda.device(p.device):
+                with torch.cuda.device(p.device), host_io():
                     plan = self._plans[key] = _VisualPlan(get_context(p.device), self.config, lambda n: params[n].data, N)
-        with torch.cuda.device(p.device):
+        from ._lib import host_io
+        with torch.cuda.device(p.device), host_io():
             return plan.run(images)
 
 

@@ -183,7 +183,7 @@ class _TextTower(ParamTree):
         if p.device.type != "cuda":
             raise RuntimeError("upgpt_amd.%s computes only through the HIP kernels on an MI355X: move it to 'cuda' first. "
                                "There is no CPU fallback." % type(self).__name__)
-        from ._lib import PLAN_LOCK, current_lane, get_context
+        from ._lib import PLAN_LOCK, current_lane, get_context, host_io
         with PLAN_LOCK:  # (execution lanes: a plan — buffers and packed weights — per (batch, lane))
             fp = weights_fingerprint(self)
             if fp != self._fp:
@@ -196,10 +196,11 @@ class _TextTower(ParamTree):
                 if len(mine) >= 4:
                     self._plans.pop(mine[0])
                 params = dict(self.named_parameters())
-                with torch.cuda.device(p.device):
+                with torch.cuda.device(p.device), host_io():
                     plan = self._plans[key] = _TextPlan(get_context(p.device), self.config, lambda n: params[n].data, B,
                                                         names=self.NAMES)
-        with torch.cuda.device(p.device):
+        from ._lib import host_io
+        with torch.cuda.device(p.device), host_io():  # (token ids come from the host: _lib.host_io)
             return plan.run(input_ids)
 
 

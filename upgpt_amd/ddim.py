@@ -9,12 +9,14 @@ for all S steps and the cross-attention K/V of the context are computed once bef
 loop.  The reference instead runs ~1-2 k ATen launches plus four torch.full allocations
 per step from Python (ddim.py:140-203).
 """
+import contextlib
 import os
 
 import numpy as np
 import torch
 
 from ._check import require
+from ._lib import host_io
 from .schedule import (ddim_coefficient_table, extract_into_tensor, make_ddim_sampling_parameters,
                        make_ddim_timesteps)
 
@@ -43,6 +45,7 @@ class DDIMSampler(object):
         setattr(self, name, attr)
 
     def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
+        self._sched_key = None  # (sample() keeps the tables of an unchanged (S, eta); a direct call always rebuilds)
         self.ddim_timesteps = make_ddim_timesteps(ddim_discr_method=ddim_discretize,
                                                   num_ddim_timesteps=ddim_num_steps,
                                                   num_ddpm_timesteps=self.ddpm_num_timesteps, verbose=verbose)
@@ -83,7 +86,14 @@ class DDIMSampler(object):
             cbs = (first[0] if isinstance(first, (list, tuple)) else first).shape[0]
             if cbs != batch_size:
                 print(f"Warning: Got {cbs} conditionings but batch-size is {batch_size}")
-        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
+        # the schedule tables of (S, eta) are kept between calls (the reference rebuilds and re-uploads them every time,
+        # ddim.py:86): with several batches in flight a blocking upload per call serialises the lanes (_lib.host_io)
+        acp = self.model.alphas_cumprod
+        key = (int(S), float(eta), id(self.model), acp.data_ptr(), int(getattr(acp, "_version", 0)), str(acp.device))
+        if verbose or getattr(self, "_sched_key", None) != key:
+            with host_io():
+                self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
+            self._sched_key = key
         C, H, W = shape
         size = (batch_size, C, H, W)
         print(f"Data shape for DDIM sampling is {size}, eta {eta}")
@@ -124,40 +134,49 @@ class DDIMSampler(object):
                 from .engine import SamplerState
                 st = SamplerState(plan, C, cfg=cfg)
                 setattr(plan, attr, st)
-            img = torch.randn(shape, device=dev) if x_T is None else x_T.to(dev, torch.float32)
-            st.x.copy_(img)
-            plan.load_x_nchw(torch.cat([st.x, st.x]) if cfg else st.x, 0, 0)
-            ncat = 0
-            if c_concat is not None:
-                ncat = c_concat.shape[1]
-                plan.load_x_nchw(c_concat, C, plan.cin_pad)
-            require(C + ncat == unet.in_channels, lambda: "latent %d + concat %d != UNet in_channels %d" % ( C, ncat, unet.in_channels), ValueError)
             order = np.arange(S)[::-1].copy()  # loop order: descending DDIM index
-            plan.t_rows.copy_(torch.as_tensor(np.asarray(timesteps)[order].astype(np.float32)))
-            plan.load_context(c_cross)
-            st.coefs.copy_(ddim_coefficient_table(self.ddim_alphas, self.ddim_alphas_prev, self.ddim_sigmas,
-                                                  self.ddim_sqrt_one_minus_alphas, order))
             sig = torch.as_tensor(np.asarray(self.ddim_sigmas, dtype=np.float64)).float()[torch.as_tensor(order)]
             with_noise = bool((sig != 0).any())
-            # RNG consumption follows the reference: p_sample_ddim draws noise_like(x.shape) in EVERY step, also when
-            # sigma_t == 0 (ddim.py:200, util.py:264-267), so after sample() the device generator has advanced by S
-            # draws of the latent's shape — a caller that seeds once and samples several batches (inference.ipynb)
-            # sees the same stream positions.  The S draws happen here, before the captured loop, one call per step.
-            if with_noise:
-                nz = st.ensure_noise()
-                if normals_sequence is not None:
-                    ns = normals_sequence if torch.is_tensor(normals_sequence) else torch.stack(
-                        list(normals_sequence))
-                    nz.copy_(ns.to(dev, torch.float32).reshape(S, -1))
-                else:
+            f64b = lambda v: np.asarray(v, dtype=np.float64).tobytes()
+            tkey = (np.asarray(timesteps).tobytes(), f64b(self.ddim_alphas), f64b(self.ddim_alphas_prev), f64b(self.ddim_sigmas))
+            fresh = getattr(st, "_table_key", None) != tkey  # (timestep rows / coefficient table of this plan: upload once)
+            on_host = any(t is not None and torch.is_tensor(t) and not t.is_cuda for t in (x_T, c_concat, c_cross))
+            # uploads from the host never overlap another lane's graph capture (_lib.host_io); a call with everything on
+            # the device and an unchanged schedule uploads nothing and takes no lock
+            with (host_io() if (fresh or on_host or with_noise) else contextlib.nullcontext()):
+                img = torch.randn(shape, device=dev) if x_T is None else x_T.to(dev, torch.float32)
+                st.x.copy_(img)
+                plan.load_x_nchw(torch.cat([st.x, st.x]) if cfg else st.x, 0, 0)
+                ncat = 0
+                if c_concat is not None:
+                    ncat = c_concat.shape[1]
+                    plan.load_x_nchw(c_concat, C, plan.cin_pad)
+                require(C + ncat == unet.in_channels, lambda: "latent %d + concat %d != UNet in_channels %d" % ( C, ncat, unet.in_channels), ValueError)
+                plan.load_context(c_cross)
+                if fresh:
+                    plan.t_rows.copy_(torch.as_tensor(np.asarray(timesteps)[order].astype(np.float32)))
+                    st.coefs.copy_(ddim_coefficient_table(self.ddim_alphas, self.ddim_alphas_prev, self.ddim_sigmas,
+                                                          self.ddim_sqrt_one_minus_alphas, order))
+                    st._table_key = tkey
+                # RNG consumption follows the reference: p_sample_ddim draws noise_like(x.shape) in EVERY step, also when
+                # sigma_t == 0 (ddim.py:200, util.py:264-267), so after sample() the device generator has advanced by S
+                # draws of the latent's shape — a caller that seeds once and samples several batches (inference.ipynb)
+                # sees the same stream positions.  The S draws happen here, before the captured loop, one call per step.
+                if with_noise:
+                    nz = st.ensure_noise()
+                    if normals_sequence is not None:
+                        ns = normals_sequence if torch.is_tensor(normals_sequence) else torch.stack(
+                            list(normals_sequence))
+                        nz.copy_(ns.to(dev, torch.float32).reshape(S, -1))
+                    else:
+                        for i in range(S):
+                            nz[i].copy_(torch.randn(shape, device=dev).reshape(-1))
+                    nz.mul_((sig * float(temperature)).to(dev)[:, None])
+                elif normals_sequence is None:
                     for i in range(S):
-                        nz[i].copy_(torch.randn(shape, device=dev).reshape(-1))
-                nz.mul_((sig * float(temperature)).to(dev)[:, None])
-            elif normals_sequence is None:
-                for i in range(S):
-                    torch.randn(shape, device=dev)  # (sigma = 0: the draw is discarded, as in the reference)
-            plan.step.zero_()
-            plan.prep.run()
+                        torch.randn(shape, device=dev)  # (sigma = 0: the draw is discarded, as in the reference)
+                plan.step.zero_()
+                plan.prep.run()
             intermediates = {"x_inter": [st.x.clone()], "pred_x0": [st.x.clone()]}
             print(f"Running DDIM Sampling with {S} timesteps")
             # steps whose result the host looks at (callbacks, logged intermediates: ddim.py:139-147) end a graph; the

@@ -449,19 +449,20 @@ class SamplerState:
             p = self.plan
             if with_noise:
                 self.ensure_noise()
-            side = torch.cuda.Stream(device=p.dev)
-            side.wait_stream(torch.cuda.current_stream(p.dev))
-            sp = side.cuda_stream
-            p.ctx._chk(p.lib.upk_graph_begin(p.hctx, sp))
-            try:
-                for _ in range(int(nsteps)):
-                    p.body.run(sp)
-                    self._emit_tail(sp, with_noise, scale)
-            finally:
-                gh = C.c_void_p()
-                rc = p.lib.upk_graph_end(p.hctx, sp, C.byref(gh))
-            p.ctx._chk(rc)
-            torch.cuda.current_stream(p.dev).wait_stream(side)
+            with L.host_io():  # (no other lane uploads from the host while this thread captures)
+                side = torch.cuda.Stream(device=p.dev)
+                side.wait_stream(torch.cuda.current_stream(p.dev))
+                sp = side.cuda_stream
+                p.ctx._chk(p.lib.upk_graph_begin(p.hctx, sp))
+                try:
+                    for _ in range(int(nsteps)):
+                        p.body.run(sp)
+                        self._emit_tail(sp, with_noise, scale)
+                finally:
+                    gh = C.c_void_p()
+                    rc = p.lib.upk_graph_end(p.hctx, sp, C.byref(gh))
+                p.ctx._chk(rc)
+                torch.cuda.current_stream(p.dev).wait_stream(side)
             # one sample() makes up to three graphs per (noise, scale) (full groups of steps, the remainder, single steps
             # around a callback): 16 graphs = five guidance scales in rotation; least recently used first
             if len(self.graphs) >= 16:

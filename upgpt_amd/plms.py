@@ -12,6 +12,7 @@ import torch
 
 from .ddim import DDIMSampler
 from ._check import require
+from ._lib import host_io
 
 # Adams-Bashforth weights on [e_t, e_{t-1}, e_{t-2}, e_{t-3}] by available history (plms.py:224-234)
 _AB = {1: (3 / 2, -1 / 2), 2: (23 / 12, -16 / 12, 5 / 12), 3: (55 / 24, -59 / 24, 37 / 24, -9 / 24)}
@@ -28,7 +29,8 @@ class PLMSSampler(DDIMSampler):
                img_callback=None, quantize_x0=False, eta=0., mask=None, x0=None, temperature=1., noise_dropout=0.,
                score_corrector=None, corrector_kwargs=None, verbose=True, x_T=None, log_every_t=100,
                unconditional_guidance_scale=1., unconditional_conditioning=None, **kwargs):
-        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
+        with host_io():
+            self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
         C, H, W = shape
         size = (batch_size, C, H, W)
         print(f"Data shape for PLMS sampling is {size}")
@@ -107,25 +109,26 @@ class PLMSSampler(DDIMSampler):
             if st is None:
                 st = SamplerState(plan, C, cfg=cfg, plms=True)
                 setattr(plan, attr, st)
-            img = torch.randn(shape, device=dev) if x_T is None else x_T.to(dev, torch.float32)
-            st.x.copy_(img)
-            plan.load_x_nchw(torch.cat([st.x, st.x]) if cfg else st.x, 0, 0)
-            if c_concat is not None:
-                plan.load_x_nchw(c_concat, C, plan.cin_pad)
-            require(C + (0 if c_concat is None else c_concat.shape[1]) == unet.in_channels, "latent + concat channels != UNet in_channels", ValueError)
-            order = np.arange(S)[::-1].copy()
-            t_desc = np.asarray(timesteps)[order].astype(np.float32)
-            # evaluation k runs at: t_0, then (x~, t_next = t_1) for the Euler corrector, then t_1, t_2, ...
-            t_eval = np.concatenate([t_desc[:1], t_desc[min(1, S - 1):min(1, S - 1) + 1], t_desc[1:]])
-            require(t_eval.shape[0] == S + 1, "PLMS evaluates S + 1 times", RuntimeError)
-            plan.t_rows.copy_(torch.as_tensor(t_eval))
-            plan.load_context(c_cross)
-            st.coefs[:S].copy_(ddim_coefficient_table(self.ddim_alphas, self.ddim_alphas_prev, self.ddim_sigmas,
-                                                      self.ddim_sqrt_one_minus_alphas, order))
-            for _ in range(S + 1):  # the reference draws (and, eta being 0, discards) one noise tensor per update:
-                torch.randn(shape, device=dev)  # plms.py get_x_prev_and_pred_x0 — same generator state afterwards
-            plan.step.zero_()
-            plan.prep.run()
+            with host_io():
+                img = torch.randn(shape, device=dev) if x_T is None else x_T.to(dev, torch.float32)
+                st.x.copy_(img)
+                plan.load_x_nchw(torch.cat([st.x, st.x]) if cfg else st.x, 0, 0)
+                if c_concat is not None:
+                    plan.load_x_nchw(c_concat, C, plan.cin_pad)
+                require(C + (0 if c_concat is None else c_concat.shape[1]) == unet.in_channels, "latent + concat channels != UNet in_channels", ValueError)
+                order = np.arange(S)[::-1].copy()
+                t_desc = np.asarray(timesteps)[order].astype(np.float32)
+                # evaluation k runs at: t_0, then (x~, t_next = t_1) for the Euler corrector, then t_1, t_2, ...
+                t_eval = np.concatenate([t_desc[:1], t_desc[min(1, S - 1):min(1, S - 1) + 1], t_desc[1:]])
+                require(t_eval.shape[0] == S + 1, "PLMS evaluates S + 1 times", RuntimeError)
+                plan.t_rows.copy_(torch.as_tensor(t_eval))
+                plan.load_context(c_cross)
+                st.coefs[:S].copy_(ddim_coefficient_table(self.ddim_alphas, self.ddim_alphas_prev, self.ddim_sigmas,
+                                                          self.ddim_sqrt_one_minus_alphas, order))
+                for _ in range(S + 1):  # the reference draws (and, eta being 0, discards) one noise tensor per update:
+                    torch.randn(shape, device=dev)  # plms.py get_x_prev_and_pred_x0 — same generator state afterwards
+                plan.step.zero_()
+                plan.prep.run()
             intermediates = {"x_inter": [st.x.clone()], "pred_x0": [st.x.clone()]}
             print(f"Running PLMS Sampling with {S} timesteps")
             for k in range(S + 1):

@@ -67,7 +67,8 @@ class UNetModel(ParamTree):
             fp = fpf()
         ent = self._packed.get(tag)
         if ent is None or ent[0] != fp:
-            with torch.cuda.device(dev):
+            from ._lib import host_io
+            with torch.cuda.device(dev), host_io():
                 pk = PackedUNet(ctx, self.arch, get)
             self._packed[tag] = (fp, pk)
             for k in [k for k in self._plans if k[0] == tag]:
@@ -89,7 +90,8 @@ class UNetModel(ParamTree):
             mine = [k for k in self._plans if k[-1] == key[-1]]
             if len(mine) >= 8:  # bound device memory held by stale shapes — per lane: another lane's plans may be executing
                 self._plans.pop(mine[0]).close()
-            with torch.cuda.device(ctx.device):
+            from ._lib import host_io
+            with torch.cuda.device(ctx.device), host_io():  # (descriptor tables are uploaded from the host)
                 pl = UNetPlan(ctx, pk, B, H, W, n_ctx, rows, mode)
                 pl.apply_tuning(tune_missing=os.environ.get("UPGPT_AUTOTUNE", "0") == "1")
             self._plans[key] = pl

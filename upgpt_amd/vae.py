@@ -10,6 +10,7 @@ from .arch import VAEArch
 from .config import instantiate_from_config
 from .params import ParamTree, weights_fingerprint
 from ._check import require
+from ._lib import host_io
 
 
 class DiagonalGaussianDistribution(object):
@@ -94,7 +95,7 @@ class AutoencoderKL(ParamTree):
         fp = weights_fingerprint(self)
         if self._packed is None or self._packed[0] != fp:
             params = dict(self.named_parameters())
-            with torch.cuda.device(p.device):
+            with torch.cuda.device(p.device), host_io():
                 self._packed = (fp, PackedVAEDecoder(ctx, self.arch, lambda n: params[n].data))
             self._plans = {}
         from ._lib import current_lane
@@ -103,7 +104,7 @@ class AutoencoderKL(ParamTree):
             mine = [k for k in self._plans if k[-1] == key[-1]]
             if len(mine) >= 4:  # (per lane: another lane's plans may be executing)
                 self._plans.pop(mine[0])
-            with torch.cuda.device(p.device):
+            with torch.cuda.device(p.device), host_io():
                 self._plans[key] = VAEDecodePlan(ctx, self._packed[1], B, h, w, scale_factor)
                 self._plans[key].apply_tuning(tune_missing=os.environ.get("UPGPT_AUTOTUNE", "0") == "1")
         return self._plans[key]
@@ -133,7 +134,7 @@ class AutoencoderKL(ParamTree):
         fp = weights_fingerprint(self)
         if self._packed_enc is None or self._packed_enc[0] != fp:
             params = dict(self.named_parameters())
-            with torch.cuda.device(p.device):
+            with torch.cuda.device(p.device), host_io():
                 self._packed_enc = (fp, PackedVAEEncoder(ctx, self.arch, lambda n: params[n].data))
             self._enc_plans = {}
         from ._lib import current_lane
@@ -142,7 +143,7 @@ class AutoencoderKL(ParamTree):
             mine = [k for k in self._enc_plans if k[-1] == key[-1]]
             if len(mine) >= 4:
                 self._enc_plans.pop(mine[0])
-            with torch.cuda.device(p.device):
+            with torch.cuda.device(p.device), host_io():
                 self._enc_plans[key] = VAEEncodePlan(ctx, self._packed_enc[1], B, H, W)
                 self._enc_plans[key].apply_tuning(tune_missing=os.environ.get("UPGPT_AUTOTUNE", "0") == "1")
         return self._enc_plans[key]
