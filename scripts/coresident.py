@@ -8,11 +8,13 @@ import upgpt_amd
 from upgpt_amd import _lib as L
 from upgpt_amd.lanes import LanePool
 SHAPES = {"c3_M8192": (3, 224, 224, 32, 32), "c3_M2048": (3, 448, 448, 16, 16), "c3_M512": (3, 896, 896, 8, 8),
-          "k1_M2048": (1, 448, 448, 16, 16), "k1_M512": (1, 896, 896, 8, 8)}
+          "k1_M2048": (1, 448, 448, 16, 16), "k1_M512": (1, 896, 896, 8, 8),
+          "v128": (3, 128, 128, 256, 256), "v256": (3, 256, 256, 128, 128), "v512": (3, 512, 512, 64, 64), "v512s": (3, 512, 512, 32, 32)}
 CFGS = sys.argv[2:] or ["1x7x4x1k4w3:1", "1x7x4x1k2w3:1", "4x2x2x2k2w3:1", "2x4x4x1k2w3:1", "2x4x2x2k2w3:1", "2x7x2x2k2w3:1", "2x2x2x2k2w3:1", "2x2x2x2k4w3:1"]
 name = sys.argv[1] if len(sys.argv) > 1 else "c3_M8192"
 ks, cin, cout, H, W = SHAPES[name]
-B, R, NL = 8, 20, 4
+B, NL = 8, 4
+R = 20 if H * W <= 1024 else 3
 pool = LanePool(NL)
 print("streams on distinct queues:", pool.queue_probe)
 ctxs = [L.get_context(0, lane=i) for i in range(NL)]

@@ -40,11 +40,13 @@ def run(L, wls, streams, n):
     return time.perf_counter() - t0, outs
 
 
+from upgpt_amd.lanes import LanePool
 wls, streams = [], []
 for L in LANES:
     while len(wls) < L:
         wls.append(bench.Workload(model, 8, hw, 50, seed=len(wls)))
-        streams.append(torch.cuda.Stream())
+    pool = LanePool(L)  # (streams probed to sit on distinct hardware queues: unprobed ones gave 60-80 img/s at random)
+    streams = [s if s is not None else torch.cuda.current_stream() for s in pool.streams]
     for i in range(L):  # warm every lane serially (plans, tuning lookups, graphs)
         run(1, [wls[i]], [streams[i]], 1) if i == 0 else None
     with model.ema_scope(), contextlib.redirect_stdout(io.StringIO()):
