@@ -7,6 +7,8 @@ the Adams-Bashforth combination and classifier-free guidance live in the update 
 embeddings of all evaluations are precomputed like DDIM's.  Anything else (masks, score correctors, noise
 dropout) runs on the general path: one UNetModel.forward per model evaluation driven from Python.
 """
+import contextlib
+
 import numpy as np
 import torch
 
@@ -29,8 +31,12 @@ class PLMSSampler(DDIMSampler):
                img_callback=None, quantize_x0=False, eta=0., mask=None, x0=None, temperature=1., noise_dropout=0.,
                score_corrector=None, corrector_kwargs=None, verbose=True, x_T=None, log_every_t=100,
                unconditional_guidance_scale=1., unconditional_conditioning=None, **kwargs):
-        with host_io():
-            self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
+        acp = self.model.alphas_cumprod  # (tables of an unchanged (S, eta) are kept between calls, as in DDIMSampler.sample)
+        key = (int(S), float(eta), id(self.model), acp.data_ptr(), int(getattr(acp, "_version", 0)), str(acp.device))
+        if verbose or getattr(self, "_sched_key", None) != key:
+            with host_io():
+                self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
+            self._sched_key = key
         C, H, W = shape
         size = (batch_size, C, H, W)
         print(f"Data shape for PLMS sampling is {size}")
@@ -109,22 +115,28 @@ class PLMSSampler(DDIMSampler):
             if st is None:
                 st = SamplerState(plan, C, cfg=cfg, plms=True)
                 setattr(plan, attr, st)
-            with host_io():
+            order = np.arange(S)[::-1].copy()
+            t_desc = np.asarray(timesteps)[order].astype(np.float32)
+            # evaluation k runs at: t_0, then (x~, t_next = t_1) for the Euler corrector, then t_1, t_2, ...
+            t_eval = np.concatenate([t_desc[:1], t_desc[min(1, S - 1):min(1, S - 1) + 1], t_desc[1:]])
+            require(t_eval.shape[0] == S + 1, "PLMS evaluates S + 1 times", RuntimeError)
+            f64b = lambda v: np.asarray(v, dtype=np.float64).tobytes()
+            tkey = (t_eval.tobytes(), f64b(self.ddim_alphas), f64b(self.ddim_alphas_prev), f64b(self.ddim_sigmas))
+            fresh = getattr(st, "_table_key", None) != tkey
+            on_host = any(t is not None and torch.is_tensor(t) and not t.is_cuda for t in (x_T, c_concat, c_cross))
+            with (host_io() if (fresh or on_host) else contextlib.nullcontext()):  # (ddim.py _fast_sampling: same rule)
                 img = torch.randn(shape, device=dev) if x_T is None else x_T.to(dev, torch.float32)
                 st.x.copy_(img)
                 plan.load_x_nchw(torch.cat([st.x, st.x]) if cfg else st.x, 0, 0)
                 if c_concat is not None:
                     plan.load_x_nchw(c_concat, C, plan.cin_pad)
                 require(C + (0 if c_concat is None else c_concat.shape[1]) == unet.in_channels, "latent + concat channels != UNet in_channels", ValueError)
-                order = np.arange(S)[::-1].copy()
-                t_desc = np.asarray(timesteps)[order].astype(np.float32)
-                # evaluation k runs at: t_0, then (x~, t_next = t_1) for the Euler corrector, then t_1, t_2, ...
-                t_eval = np.concatenate([t_desc[:1], t_desc[min(1, S - 1):min(1, S - 1) + 1], t_desc[1:]])
-                require(t_eval.shape[0] == S + 1, "PLMS evaluates S + 1 times", RuntimeError)
-                plan.t_rows.copy_(torch.as_tensor(t_eval))
                 plan.load_context(c_cross)
-                st.coefs[:S].copy_(ddim_coefficient_table(self.ddim_alphas, self.ddim_alphas_prev, self.ddim_sigmas,
-                                                          self.ddim_sqrt_one_minus_alphas, order))
+                if fresh:
+                    plan.t_rows.copy_(torch.as_tensor(t_eval))
+                    st.coefs[:S].copy_(ddim_coefficient_table(self.ddim_alphas, self.ddim_alphas_prev, self.ddim_sigmas,
+                                                              self.ddim_sqrt_one_minus_alphas, order))
+                    st._table_key = tkey
                 for _ in range(S + 1):  # the reference draws (and, eta being 0, discards) one noise tensor per update:
                     torch.randn(shape, device=dev)  # plms.py get_x_prev_and_pred_x0 — same generator state afterwards
                 plan.step.zero_()
