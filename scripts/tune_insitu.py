@@ -320,6 +320,8 @@ if START_CHIP:  # every shape whose final choice differs from the one the run st
         if fin and fin != ORIG.get(key):
             old = ent.get(key) or TUNE_CACHE.get(key) or [0, 1, 0.0, 0.0]
             ent[key] = [fin[0], fin[1], old[2], old[3]]
+if LANES > 1:
+    ent.update(TUNE_CACHE_LANES.meta)
 ent["__configs__"] = names  # (the indices refer to THIS library's configuration list: TuneCache.bind)
 json.dump(ent, open(out, "w"), indent=0, sort_keys=True)
 json.dump({k: [list(v[0]) if v[0] else None, list(v[1]), v[2], v[3]] for k, v in changed.items()},

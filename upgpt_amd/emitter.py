@@ -474,6 +474,12 @@ class Emitter:
         if K.MLP_FUSE == "0" or t2.C != t2.ld:
             return None
         M, C_ = t2.M, t2.C
+        if (K.MLP_FUSE == "auto" and L.concurrency() > 1 and os.environ.get("UPGPT_LANES_TUNING", "1") == "1"
+                and M in TUNE_CACHE_LANES.meta.get("__unfuse_mlp_M__", ())):
+            # several batches in flight: the kernel holds every CU with one register-heavy workgroup that streams both
+            # weights (21 us of chip time per launch); GEGLU + (ff.net.2 o proj_out) as two launches on tiles tuned for a
+            # shared chip cost less (forward in flight 1.524 -> 1.490 ms) — for the row counts the table lists
+            return None
         rows = self.mlp_rows(M)
         d = L.MlpDesc()
         d.x, d.ldx, d.m, d.c, d.inner = t2.t.data_ptr(), t2.ld, M, C_, pw1.n_out

@@ -22,6 +22,9 @@ class TuneCache:
             except Exception:
                 self.d = {}
         self.names = self.d.pop("__configs__", None)
+        # other "__...__" keys are decisions that go with the table (e.g. "__unfuse_mlp_M__": row counts for which the fused
+        # feed-forward tail loses to two launches tuned for a shared chip); kept apart from the shape entries
+        self.meta = {k: self.d.pop(k) for k in list(self.d) if k.startswith("__")}
         self._bound = False
 
     def bind(self, lib):
@@ -68,6 +71,7 @@ class TuneCache:
 
     def save(self, path=None):
         out = dict(self.d)
+        out.update(self.meta)
         if self.names is not None:
             out["__configs__"] = self.names
         with open(path or self.path, "w") as f:
