@@ -14,6 +14,15 @@ from upgpt_amd.ddim import DDIMSampler
 from upgpt_amd.lanes import LanePool
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _one_batch_in_flight_afterwards():
+    """A LanePool with more than one lane switches the process to the shared-chip launch choices (_lib.concurrency());
+    the tests after this file describe one forward with the chip to itself."""
+    yield
+    L.set_concurrency(1)
+
 G = os.path.join(os.path.dirname(__file__), "golden")
 _cache = {}
 
