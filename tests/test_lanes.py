@@ -151,7 +151,8 @@ def test_throughput_overlay_is_consulted_only_with_several_batches_in_flight():
     for k, v in TUNE_CACHE_LANES.d.items():
         assert k.startswith("M") and "_N" in k and len(v) == 4 and int(v[1]) >= 1
     assert L.concurrency() == 1
-    LanePool(3, "cpu")
+    with LanePool(3, "cpu") as pool:
+        assert L.concurrency() == 1 and pool.n == 3
     assert L.concurrency() == 1
     L.set_concurrency(4)
     try:

@@ -9,6 +9,11 @@ buffers, captured step graphs), its own stream and its own host thread.  The pac
 sample() call is still one bs = B batch with the reference's call surface, and a lane's results are bit-identical to
 the serial path's (tests/test_lanes_gpu.py).  This is the serving shape of the path — independent requests of one
 batch each — not a larger batch: the batch of a UNetModel.forward does not change.
+
+While a pool with more than one lane exists, plans are built with the launch choices tuned for a shared chip
+(tuning.TUNE_CACHE_LANES: chosen by chip time with four chains in flight — few large tiles instead of one small tile per CU),
+and graph captures / plan construction / uploads from pageable host memory are serialised against each other
+(_lib.host_io; a steady-state sample() with its inputs on the device uploads nothing).  DESIGN.md 13.
 """
 import contextlib
 import os
@@ -118,6 +123,20 @@ class LanePool:
             with cond:
                 errors.append(e)
                 cond.notify_all()
+
+    def close(self):
+        """Back to one batch in flight: plans built from now on take the single-forward launch choices again (the lanes'
+        contexts, plans and graphs stay cached for the next pool)."""
+        if self.gpu and self.n > 1:
+            from ._lib import set_concurrency
+            set_concurrency(1)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def lane_step_ms(self):
         """Device time of every step of the last run() on its lane, per lane: [[ms, ...] for each lane] (synchronises)."""
