@@ -159,3 +159,53 @@ def test_throughput_overlay_is_consulted_only_with_several_batches_in_flight():
         assert L.concurrency() == 4
     finally:
         L.set_concurrency(1)
+
+
+def test_tune_cache_keeps_table_level_decisions_apart_from_shape_entries(tmp_path):
+    """"__...__" keys other than "__configs__" (e.g. the row counts whose feed-forward tail runs unfused on a shared chip)
+    survive load -> save and never look like shape entries."""
+    import json
+    from upgpt_amd.tuning import TuneCache, TUNE_CACHE_LANES
+    p = tmp_path / "t.json"
+    p.write_text(json.dumps({"__configs__": ["a", "b"], "__unfuse_mlp_M__": [8192], "M1_N2_C3+0_k1s1_f0_r000": [1, 1, 2.0, 3.0]}))
+    c = TuneCache(str(p))
+    assert c.meta == {"__unfuse_mlp_M__": [8192]} and list(c.d) == ["M1_N2_C3+0_k1s1_f0_r000"] and c.names == ["a", "b"]
+    c.save(str(tmp_path / "u.json"))
+    back = json.loads((tmp_path / "u.json").read_text())
+    assert back["__unfuse_mlp_M__"] == [8192] and back["__configs__"] == ["a", "b"] and "M1_N2_C3+0_k1s1_f0_r000" in back
+    assert 8192 in TUNE_CACHE_LANES.meta.get("__unfuse_mlp_M__", [])
+
+
+def test_host_io_is_free_with_one_batch_in_flight_and_exclusive_with_several():
+    order = []
+    with L.host_io():  # (concurrency 1: nothing to take)
+        with L.host_io():
+            order.append("nested")
+    L.set_concurrency(4)
+    try:
+        inside = threading.Event()
+        release = threading.Event()
+
+        def holder():
+            with L.host_io():
+                inside.set()
+                release.wait(5)
+                order.append("holder out")
+
+        def waiter():
+            inside.wait(5)
+            with L.host_io():
+                order.append("waiter in")
+
+        ts = [threading.Thread(target=holder), threading.Thread(target=waiter)]
+        for t in ts:
+            t.start()
+        inside.wait(5)
+        time.sleep(0.05)
+        assert "waiter in" not in order  # the second thread is held at the lock
+        release.set()
+        for t in ts:
+            t.join(5)
+        assert order == ["nested", "holder out", "waiter in"]
+    finally:
+        L.set_concurrency(1)
