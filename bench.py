@@ -206,7 +206,7 @@ def lanes_class_profile(model, pool, wl, reps=8, ncand=6):
     plans, streams = [], []
     with model.ema_scope():
         for i in range(pool.n):
-            with upgpt_amd.lane(i):
+            with pool.lane(i):
                 plans.append(unet.plan(wl.B, wl.hw[0], wl.hw[1], 87, wl.S, "sampler"))
             streams.append(pool.streams[i] if pool.streams[i] is not None else torch.cuda.current_stream())
 

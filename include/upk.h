@@ -497,87 +497,6 @@ long long upk_kernel_launches(upk_ctx* ctx, int reset);
 int upk_advance_step(upk_ctx* ctx, int32_t* step, upk_stream stream);
 
 /* ------------------------------------------------------------------ */
-/* Per-XCD persistent engine: a whole SpatialTransformer as ONE launch.  */
-/* Replaces the launch chain behind attention.py:250-261 (GroupNorm ->   */
-/* proj_in -> BasicTransformerBlock :211-215 -> proj_out + residual).    */
-/* ------------------------------------------------------------------ */
-/* MI355X is eight XCDs of 32 CUs, each with its own 4 MB L2, and every op of a transformer block is per-sample
- * (SURVEY.md 8e).  upk_xcd_run_f16 launches 256 persistent workgroups (one per CU); a workgroup reads the XCD it runs on
- * from HW_REG_XCC_ID, takes a rank among that XCD's workgroups from an arrival counter, and XCD x then works on samples
- * x, x + 8, ... through a list of PHASES.  Inside a phase the 32 CUs of the XCD split one op of one sample (a GEMM's
- * rows x output-column tiles, an attention's heads x query tiles, a GroupNorm's groups); between phases they meet at an
- * XCD-LOCAL barrier: plain stores + s_waitcnt vmcnt(0) (the data is in the XCD's L2), one L2 atomic, sc1 (L1-bypassing)
- * polls and payload loads.  Measured 1.04 us per episode against 4.9 us with agent-scope release / acquire fences and
- * ~2 us + first-touch misses for a kernel boundary (scripts/ubench/xcdsync.hip); nothing crosses an XCD.
- * Correctness never depends on which workgroup lands where: only on "workgroups that read the same XCC_ID share an L2"
- * and on every XCD receiving its 32 workgroups, which the launch verifies (else `status` is set and results are void).
- *
- * Phase kinds (fields not listed are ignored; all tensors fp16 row-major [batch * n, ld], per-sample blocks of n rows):
- *  UPK_XP_GN    y = GroupNorm(a[:, :k1]) (groups, eps; gamma / beta NULL = affine folded into the consumer's weights;
- *               silu).  CU r owns group r, the (sample, group) stays in registers between statistics and output.
- *  UPK_XP_GEMM  y = epi([a[:, :k1] | a2[:, :k2]] W^T + bias [+ res]).  W packed by upk_xcd_pack_rows order: fp16
- *               [ntiles][K/32][64 lanes][8], lane l = 16 g + i holding W[16 t + i][32 kc + 8 g .. +7] (one MFMA operand
- *               fragment = 1 KiB contiguous; a wave streams its tiles global -> VGPR, no LDS), K = k1 + k2 (k1, k2
- *               multiples of 32).  ln = 1: LayerNorm over a's k1 columns (eps; affine folded into W / bias): row statistics
- *               from the staged rows, the normalisation as algebra in the epilogue, rstd (x W'^T - mean colsum) + bias'.  The XCD's CUs form a pm x pn grid: mb (<= 64, multiple of 16) rows x
- *               ceil(ntiles / pn) tiles each; tn (1 | 2) tiles per wave pass; wk (1 | 2 | 4 | 8; 0 = 1) waves split K of a
- *               tile group and meet in LDS (then a CU takes at most tn * 8 / wk tiles).  bias fp32 [16 ntiles] in tile order.
- *               epi UPK_XE_PLAIN: y[:, :n_out]; UPK_XE_GEGLU: tiles alternate value / gate (tn = 2), y = v * gelu(g),
- *               n_out = 8 ntiles; UPK_XE_QKV: tiles < vtile0 -> y (q | k), tiles >= vtile0 -> V transposed into
- *               vt [batch, heads, dp, vt_ld].
- *  UPK_XP_ATTN  y[:, h * dp ..] = softmax(q_h K_h^T scale) V_h, q = a (lda), K = kk [batch * nkv rows, ldk] at column
- *               koff + h * dp (sample stride kbs elements), V^T = vv [batch, heads, dp, vt_ld] (sample stride vbs).
- *               4 CUs per head (heads = 8), one wave per 16 queries, online softmax; dp in {32, 64, 128}. */
-#define UPK_XP_GN 1
-#define UPK_XP_GEMM 2
-#define UPK_XP_ATTN 3
-#define UPK_XE_PLAIN 0
-#define UPK_XE_GEGLU 1
-#define UPK_XE_QKV 2
-typedef struct upk_xphase {
-  int32_t kind, n;
-  const void* a;
-  const void* a2;
-  int32_t lda, lda2, k1, k2;
-  const void* w;
-  const float* bias;
-  const void* res;
-  void* y;
-  void* vt;
-  int32_t ntiles, n_out, ldres, ldy;
-  int32_t epi, ln;
-  float eps;
-  int32_t vtile0;
-  int32_t vt_ld, heads, dp, pm;
-  int32_t pn, mb, tn, groups;
-  const void* kk;
-  const void* vv;
-  int32_t ldk, koff, nkv, silu;
-  long long kbs, vbs;
-  float scale_log2;
-  int32_t wk;
-  const float* gamma;
-  const float* beta;
-  const float* colsum; /* GEMM with ln: fp32 [16 ntiles] column sums of the fp16-rounded weight rows (tile order) */
-  int32_t nx;          /* index of the next GEMM phase of the list (its weights are prefetched during this one), -1 = none */
-  int32_t pad1;
-} upk_xphase;
-/* Bytes of the engine's synchronisation words (arrival / barrier / exit counters per XCD, status): zero them ONCE when
- * allocating; every launch leaves them zeroed again (the last workgroup of an XCD to leave resets its lines). */
-size_t upk_xcd_sync_bytes(void);
-/* Validates one phase descriptor (HOST copy): UPK_OK, or UPK_ESHAPE / UPK_EINVAL with upk_last_error set. */
-int upk_xcd_phase_check(upk_ctx* ctx, const upk_xphase* phase_host);
-/* Runs phases [0, nphases) of `phases_dev` (DEVICE array) for `batch` samples.  One launch, graph-capturable. */
-int upk_xcd_run_f16(upk_ctx* ctx, const upk_xphase* phases_dev, int nphases, int batch, void* sync_ws,
-                    upk_stream stream);
-/* Synchronising check of a finished run: *status_host = 0 ok, 1 a barrier timed out, 2 an XCD did not get exactly 32
- * workgroups (results void in both cases; the words are reset for the next launch). */
-int upk_xcd_status(upk_ctx* ctx, void* sync_ws, int* status_host);
-/* Dev tool (scripts/xcd_timeline.py): while `buf` (device, 256 * nphases * 8 int64) is set, thread 0 of every workgroup
- * stamps the shader clock per phase: start, A tile staged (GEMM phases), body done, behind the barrier.  NULL = off. */
-void upk_xcd_dev_timeline(void* buf);
-
-/* ------------------------------------------------------------------ */
 /* HIP graph helpers (the 50-step loop replays one captured step).      */
 /* ------------------------------------------------------------------ */
 typedef struct upk_graph upk_graph;

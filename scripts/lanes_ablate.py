@@ -17,7 +17,7 @@ pool = LanePool(LANES)
 print("lanes", LANES, "queues", pool.queue_probe, flush=True)
 plans = []
 for i in range(LANES):
-    with upgpt_amd.lane(i):
+    with pool.lane(i):
         p = unet.plan(8, 32, 32, 87, 50, "sampler"); p.prep.run(); plans.append(p)
 torch.cuda.synchronize()
 streams = [s if s is not None else torch.cuda.current_stream() for s in pool.streams]

@@ -206,40 +206,6 @@ def test_checkpoint_round_trip_cpu(tmp_path):
     assert not torch.equal(live, got["model_ema.diffusion_modelout2weight"])  # (the shadow is its own draw here)
 
 
-def test_xcd_gemm_grid_respects_the_engine_constraints():
-    """Host logic of the per-XCD engine (upgpt_amd/xcd_engine.py): for every GEMM of every level of the bbox / upscale /
-    tiny transformers the CU grid it picks satisfies what upk_xcd_phase_check (csrc/xcd.hip) demands — at most 32 CUs, row
-    blocks of <= 64 rows that cover the sample, the staged rows fit in LDS, (value, gate) / q|k|v tile pairs never split
-    across CUs, and a K split only where a CU's tiles fit one pass of its waves."""
-    from upgpt_amd.xcd_engine import xcd_gemm_grid
-    lds = 152 * 1024 - 640
-    shapes = []
-    for n, C, dp in [(1024, 224, 32), (768, 224, 32), (256, 448, 64), (192, 448, 64), (64, 896, 128), (48, 896, 128),
-                     (16, 896, 128), (12, 896, 128), (768, 96, 32), (48, 384, 64), (12, 384, 64), (1024, 512, 64),
-                     (256, 1024, 128)]:
-        hd, inner = 8 * dp, 4 * C
-        shapes += [(n, C // 16, C, False, False), (n, 3 * hd // 16, C, True, True), (n, C // 16, hd, False, False),
-                   (n, hd // 16, C, False, True), (n, 2 * inner // 16, C, True, True), (n, C // 16, inner + C, False, False)]
-    for n, ntiles, K, pair, ln in shapes:
-        g = xcd_gemm_grid(n, ntiles, K, pair=pair, ln=ln)
-        if g is None:
-            # refused (the caller then emits the launch chain): legitimate only when even the smallest row block that
-            # lets 32 CUs cover the sample does not fit in LDS with its K columns
-            mb_min = -(-(-(-n // 32)) // 16) * 16
-            assert mb_min * (-(-K // 128) * 128 * 2 + 96) > lds, (n, ntiles, K)
-            continue
-        pm, pn, mb, tn, wk = g
-        assert 1 <= pm * pn <= 32 and mb % 16 == 0 and 16 <= mb <= 64 and pm * mb >= n, (g, n)
-        assert tn in (1, 2) and wk in (1, 2, 4, 8)
-        tpc = -(-ntiles // pn)
-        kc_per = -(-(-(-(K // 32) // wk)) // 4) * 4
-        assert mb * (kc_per * wk * 64 + 96) <= lds, (g, K)
-        if pair:
-            assert tn == 2 and tpc % 2 == 0, (g, ntiles)
-        if wk > 1:
-            assert tpc <= tn * (8 // wk), (g, ntiles)
-
-
 def test_tune_cache_guards_and_round_trip(tmp_path):
     """TuneCache (upgpt_amd/tuning.py): put() before bind() is refused, malformed entries are dropped at bind,
     entries are re-indexed by configuration NAME when the library's list changed, and save / load round-trips."""
@@ -273,3 +239,13 @@ def test_tune_cache_guards_and_round_trip(tmp_path):
     tc2 = TuneCache(str(out))
     tc2.bind(FakeLib())
     assert tc2.get("x") == [2, 1, 1.0, 2.0] and tc2.get("k0")[0] == 1
+
+
+def test_beta_schedules_off_the_path_are_refused():
+    """Only the linear schedule exists on the UPGPT path (bbox.yaml / upscale config); the reference's other branches
+    (util.py:29-40) are refused loudly instead of being carried along untested."""
+    from upgpt_amd import schedule
+    assert schedule.make_beta_schedule("linear", 1000, 0.00085, 0.012).shape == (1000,)
+    for name in ("cosine", "sqrt_linear", "sqrt"):
+        with pytest.raises(NotImplementedError):
+            schedule.make_beta_schedule(name, 1000)

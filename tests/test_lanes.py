@@ -150,15 +150,44 @@ def test_throughput_overlay_is_consulted_only_with_several_batches_in_flight():
     assert TUNE_CACHE_LANES.names == TUNE_CACHE.names or TUNE_CACHE_LANES.names is not None
     for k, v in TUNE_CACHE_LANES.d.items():
         assert k.startswith("M") and "_N" in k and len(v) == 4 and int(v[1]) >= 1
-    assert L.concurrency() == 1
+    assert L.concurrency() == 1 and L.pools_in_flight() == 1
     with LanePool(3, "cpu") as pool:
-        assert L.concurrency() == 1 and pool.n == 3
+        assert L.concurrency() == 1 and pool.n == 3 and L.pools_in_flight() == 1  # (a CPU pool registers nothing)
+        with pool.lane(2):
+            assert L.concurrency() == 1 and L.current_lane() == 2
     assert L.concurrency() == 1
-    L.set_concurrency(4)
-    try:
+    # the switch is scoped to the thread and the block: another thread never sees it, leaving the block restores it
+    seen = []
+    with L.shared_chip(4):
         assert L.concurrency() == 4
+        with L.lane(1):  # (a bare lane keeps the enclosing scope's table)
+            assert L.concurrency() == 4
+        with L.lane(1, concurrency=2):
+            assert L.concurrency() == 2
+        assert L.concurrency() == 4
+        t = threading.Thread(target=lambda: seen.append(L.concurrency()))
+        t.start()
+        t.join()
+    assert seen == [1] and L.concurrency() == 1
+
+
+def test_a_live_gpu_pool_is_registered_until_closed_and_arms_host_io(monkeypatch):
+    """LanePool registers itself process-wide (pools_in_flight: what host_io() looks at besides the thread's own scope)
+    and close() / __exit__ / a second close() drop it again; concurrency() of threads outside its lanes stays 1."""
+    class FakePool:
+        pass
+    a, b = FakePool(), FakePool()
+    L._register_pool(a, 4)
+    L._register_pool(b, 2)
+    try:
+        assert L.pools_in_flight() == 4 and L.concurrency() == 1
+        L._unregister_pool(a)
+        assert L.pools_in_flight() == 2
+        L._unregister_pool(a)  # (idempotent)
     finally:
-        L.set_concurrency(1)
+        L._unregister_pool(a)
+        L._unregister_pool(b)
+    assert L.pools_in_flight() == 1
 
 
 def test_tune_cache_keeps_table_level_decisions_apart_from_shape_entries(tmp_path):
@@ -181,7 +210,10 @@ def test_host_io_is_free_with_one_batch_in_flight_and_exclusive_with_several():
     with L.host_io():  # (concurrency 1: nothing to take)
         with L.host_io():
             order.append("nested")
-    L.set_concurrency(4)
+    class FakePool:
+        pass
+    pool = FakePool()
+    L._register_pool(pool, 4)  # (a live pool arms the lock for every thread of the process)
     try:
         inside = threading.Event()
         release = threading.Event()
@@ -208,4 +240,4 @@ def test_host_io_is_free_with_one_batch_in_flight_and_exclusive_with_several():
             t.join(5)
         assert order == ["nested", "holder out", "waiter in"]
     finally:
-        L.set_concurrency(1)
+        L._unregister_pool(pool)

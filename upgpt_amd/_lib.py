@@ -29,7 +29,6 @@ SYMBOLS = [
     "upk_patchify_nchw_f32_f16", "upk_vit_assemble_f16", "upk_gather_rows_f16",
     "upk_advance_step", "upk_step_autoadvance", "upk_kernel_launches", "upk_graph_begin", "upk_graph_end", "upk_graph_launch", "upk_graph_destroy",
     "upk_prof_enable", "upk_prof_collect",
-    "upk_xcd_sync_bytes", "upk_xcd_phase_check", "upk_xcd_run_f16", "upk_xcd_status", "upk_xcd_dev_timeline",
 ]
 
 F_SILU, F_GEGLU, F_OUT_F32, F_OUT_NCHW_F32, F_UPSAMPLE2X, F_PAD_ASYM = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
@@ -104,30 +103,6 @@ class HblockDesc(C.Structure):
         ("vt", C.c_void_p), ("vt_ld", C.c_int32), ("hw", C.c_int32), ("rows_per_wg", C.c_int32),
         ("gn_part", C.c_void_p), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p),
         ("gn_nblk", C.c_int32), ("gn_ld", C.c_int32), ("gn_groups", C.c_int32), ("gn_eps", C.c_float),
-    ]
-
-
-XP_GN, XP_GEMM, XP_ATTN = 1, 2, 3
-XE_PLAIN, XE_GEGLU, XE_QKV = 0, 1, 2
-
-
-class XPhase(C.Structure):
-    """Mirror of struct upk_xphase (include/upk.h): one phase of the per-XCD engine."""
-    _fields_ = [
-        ("kind", C.c_int32), ("n", C.c_int32),
-        ("a", C.c_void_p), ("a2", C.c_void_p),
-        ("lda", C.c_int32), ("lda2", C.c_int32), ("k1", C.c_int32), ("k2", C.c_int32),
-        ("w", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p), ("y", C.c_void_p), ("vt", C.c_void_p),
-        ("ntiles", C.c_int32), ("n_out", C.c_int32), ("ldres", C.c_int32), ("ldy", C.c_int32),
-        ("epi", C.c_int32), ("ln", C.c_int32), ("eps", C.c_float), ("vtile0", C.c_int32),
-        ("vt_ld", C.c_int32), ("heads", C.c_int32), ("dp", C.c_int32), ("pm", C.c_int32),
-        ("pn", C.c_int32), ("mb", C.c_int32), ("tn", C.c_int32), ("groups", C.c_int32),
-        ("kk", C.c_void_p), ("vv", C.c_void_p),
-        ("ldk", C.c_int32), ("koff", C.c_int32), ("nkv", C.c_int32), ("silu", C.c_int32),
-        ("kbs", C.c_longlong), ("vbs", C.c_longlong),
-        ("scale_log2", C.c_float), ("wk", C.c_int32),
-        ("gamma", C.c_void_p), ("beta", C.c_void_p),
-        ("colsum", C.c_void_p), ("nx", C.c_int32), ("pad1", C.c_int32),
     ]
 
 
@@ -207,11 +182,6 @@ def load_library(path=None):
             "upk_graph_destroy": (C.c_int, [vp, vp]),
             "upk_prof_enable": (C.c_int, [vp, i32]),
             "upk_prof_collect": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
-            "upk_xcd_sync_bytes": (C.c_size_t, []),
-            "upk_xcd_phase_check": (C.c_int, [vp, C.POINTER(XPhase)]),
-            "upk_xcd_run_f16": (C.c_int, [vp, vp, i32, i32, vp, vp]),
-            "upk_xcd_status": (C.c_int, [vp, vp, C.POINTER(C.c_int)]),
-            "upk_xcd_dev_timeline": (None, [vp]),
         }
         require(sorted(protos) == sorted(SYMBOLS), "ctypes prototypes and SYMBOLS differ", RuntimeError)
         for name, (res, args) in protos.items():
@@ -403,18 +373,55 @@ PLAN_LOCK = threading.RLock()  # plan / packed-weight caches are built under it 
 _lane = threading.local()
 
 
-_concurrency = 1
+# ---- how many batches share the chip: scoped, not a process-wide mode switch
+# Two notions that used to be one global:
+#  * concurrency() — THREAD-scoped: the number of batches in flight the calling thread builds plans for.  It is n inside a
+#    lane of a LanePool(n) (LanePool.lane(i), what the pool's own threads run in) or inside shared_chip(n), else 1.  Plan keys
+#    carry `concurrency() > 1`, i.e. the identity of the tuning table the plan was built from (tuning.TUNE_CACHE_LANES vs the
+#    latency table), so a server that mixes pooled and un-pooled callers gives each the plans of ITS table, whatever
+#    was active when somebody else built theirs.
+#  * pools_in_flight() — process-wide: the largest live LanePool (registered at construction, dropped by close()).  Only
+#    host_io() looks at it: a capture on one thread and a pageable upload on another collide whichever table they use.
+_pools = {}
+_pools_lock = threading.Lock()
 
 
 def concurrency():
-    """How many batches the process keeps in flight per device (1 unless a LanePool with more lanes exists): plans
-    built at concurrency > 1 take the throughput-tuned launch choices (tuning.TUNE_CACHE_LANES)."""
-    return _concurrency
+    """Batches in flight the CALLING THREAD builds plans for (1 outside LanePool.lane(i) / shared_chip(n)): plans built
+    at concurrency > 1 take the throughput-tuned launch choices (tuning.TUNE_CACHE_LANES)."""
+    return getattr(_lane, "conc", 1)
 
 
 def set_concurrency(n):
-    global _concurrency
-    _concurrency = max(1, int(n))
+    """Thread-scoped setter (scripts that build lane plans from their main thread); prefer `with shared_chip(n):`."""
+    _lane.conc = max(1, int(n))
+
+
+@contextlib.contextmanager
+def shared_chip(n):
+    """Plans the calling thread builds inside this block are tuned for `n` batches sharing the chip."""
+    prev = concurrency()
+    set_concurrency(n)
+    try:
+        yield
+    finally:
+        set_concurrency(prev)
+
+
+def pools_in_flight():
+    """Lanes of the largest live LanePool of the process (1 without one)."""
+    with _pools_lock:
+        return max(_pools.values(), default=1)
+
+
+def _register_pool(pool, n):
+    with _pools_lock:
+        _pools[id(pool)] = int(n)
+
+
+def _unregister_pool(pool):
+    with _pools_lock:
+        _pools.pop(id(pool), None)
 
 
 _HOST_IO_LOCK = threading.RLock()
@@ -429,7 +436,7 @@ def host_io():
     mode), so the two never overlap.  The lane's own stream is drained BEFORE the lock is taken — a blocking upload waits
     for the stream's earlier work (the lane's previous batch, hundreds of ms in flight) and must not do that inside the
     lock.  A no-op with one batch in flight: the serial path is unchanged."""
-    if _concurrency <= 1 or _HOST_IO_OFF:
+    if (concurrency() <= 1 and pools_in_flight() <= 1) or _HOST_IO_OFF:
         yield
         return
     if torch.cuda.is_available():
@@ -444,7 +451,7 @@ def current_lane():
 
 
 @contextlib.contextmanager
-def lane(i, stream=None):
+def lane(i, stream=None, concurrency=None):
     """Everything the calling thread launches inside this block belongs to execution lane `i`: its own upk_ctx (own
     split-K workspace), its own activation buffers / plans / captured graphs (the plan caches of UNetModel and
     AutoencoderKL are keyed by lane) and, when `stream` is given, that HIP stream.  The packed weights are shared.
@@ -452,8 +459,10 @@ def lane(i, stream=None):
     kernels of one lane's latency chain fill the launch boundaries and prologues of the other's.
     Lane 0 is the default lane: code that never enters a lane behaves exactly as before."""
     require(int(i) >= 0, "lane index must be >= 0", ValueError)
-    prev = getattr(_lane, "i", 0)
+    prev, prev_c = getattr(_lane, "i", 0), getattr(_lane, "conc", 1)
     _lane.i = int(i)
+    if concurrency is not None:  # (LanePool.lane: plans built in here are tuned for that many batches in flight)
+        _lane.conc = max(1, int(concurrency))
     try:
         if stream is not None:
             with torch.cuda.stream(stream):
@@ -461,7 +470,7 @@ def lane(i, stream=None):
         else:
             yield
     finally:
-        _lane.i = prev
+        _lane.i, _lane.conc = prev, prev_c
 
 
 def get_context(device=None, lane=None):

@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.environ.get("UPK_LIB") or os.path.join(HERE, "libupk.so")  # (UPK_LIB + UPK_CXXFLAGS: dev builds)
-SOURCES = ["igemm.hip", "bigtile.hip", "astat.hip", "mlp.hip", "xblock.hip", "attention.hip", "norm.hip", "misc.hip", "xcd.hip"]
+SOURCES = ["igemm.hip", "bigtile.hip", "astat.hip", "mlp.hip", "xblock.hip", "attention.hip", "norm.hip", "misc.hip"]
 # per-file flags.  attention.hip: MFMA results straight into arch VGPRs — the softmax between the two matmuls reads
 # every score with VALU instructions, and with the accumulators in AGPRs 112 of ~600 issue slots per 64-key tile were
 # v_accvgpr moves (the kernels use < 128 registers, there is nothing to gain from the AGPR file)

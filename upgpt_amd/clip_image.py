@@ -141,16 +141,16 @@ class CLIPVisual(ParamTree):
         if p.device.type != "cuda":
             raise RuntimeError("upgpt_amd.CLIPVisual computes only through the HIP kernels on an MI355X: move it to 'cuda' "
                                "first. There is no CPU fallback.")
-        from ._lib import PLAN_LOCK, current_lane, get_context, host_io
-        with PLAN_LOCK:  # (execution lanes: a plan — buffers and packed weights — per (crop count, lane))
+        from ._lib import PLAN_LOCK, concurrency, current_lane, get_context, host_io
+        with PLAN_LOCK:  # (execution lanes: a plan — buffers and packed weights — per (crop count, tuning table, lane))
             fp = weights_fingerprint(self)
             if fp != self._fp:
                 self._plans, self._fp = {}, fp
             N = int(images.shape[0])
-            key = (N, current_lane())
+            key = (N, concurrency() > 1, current_lane())
             plan = self._plans.get(key)
             if plan is None:
-                mine = [k for k in self._plans if k[1] == key[1]]
+                mine = [k for k in self._plans if k[-1] == key[-1]]
                 if len(mine) >= 2:
                     self._plans.pop(mine[0])
                 params = dict(self.named_parameters())

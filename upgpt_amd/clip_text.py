@@ -183,16 +183,16 @@ class _TextTower(ParamTree):
         if p.device.type != "cuda":
             raise RuntimeError("upgpt_amd.%s computes only through the HIP kernels on an MI355X: move it to 'cuda' first. "
                                "There is no CPU fallback." % type(self).__name__)
-        from ._lib import PLAN_LOCK, current_lane, get_context, host_io
-        with PLAN_LOCK:  # (execution lanes: a plan — buffers and packed weights — per (batch, lane))
+        from ._lib import PLAN_LOCK, concurrency, current_lane, get_context, host_io
+        with PLAN_LOCK:  # (execution lanes: a plan — buffers and packed weights — per (batch, tuning table, lane))
             fp = weights_fingerprint(self)
             if fp != self._fp:
                 self._plans, self._fp = {}, fp
             B = int(input_ids.shape[0])
-            key = (B, current_lane())
+            key = (B, concurrency() > 1, current_lane())
             plan = self._plans.get(key)
             if plan is None:
-                mine = [k for k in self._plans if k[1] == key[1]]
+                mine = [k for k in self._plans if k[-1] == key[-1]]
                 if len(mine) >= 4:
                     self._plans.pop(mine[0])
                 params = dict(self.named_parameters())

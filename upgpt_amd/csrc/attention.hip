@@ -718,8 +718,12 @@ static int attention_impl(upk_ctx* ctx, const void* q, int ldq, long long qbs, c
     case 512:
       // the VAE mid-block attention on LDS-shared key tiles (attn_wide_kernel): one head, whole 32-key tiles, rows of K
       // that are exactly one 1 KiB request; anything else falls through to the direct kernel below
-      if (heads == 1 && !causal && (n_kv & 31) == 0 && ldk >= 512 && (vt_ld & 7) == 0 && !getenv("UPK_ATTN_WIDE_OFF")) {
-        static unsigned long long wide_mask = 0;
+      // (16-byte LDS-DMA pieces and f16x8 Q loads: every row / sample stride a multiple of 8 halves, 16-byte bases)
+      static const bool wide_off = getenv("UPK_ATTN_WIDE_OFF") != nullptr;  // (read once: lane threads call this concurrently)
+      if (heads == 1 && !causal && (n_kv & 31) == 0 && ldk >= 512 && !wide_off &&
+          ((ldk | ldq | vt_ld) & 7) == 0 && ((kbs | qbs) & 7) == 0 &&
+          (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15) == 0) {
+        static unsigned long long wide_mask = 0;  // (set under upk_lds_attr_once's mutex)
         int rcw = upk_lds_attr_once(ctx, (const void*)attn_wide_kernel<512>, &wide_mask);
         if (rcw != UPK_OK) return rcw;
         const size_t lds = 2 * (32 * (512 * 2 + 32) + 512 * 64);

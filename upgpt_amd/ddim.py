@@ -138,8 +138,13 @@ class DDIMSampler(object):
             sig = torch.as_tensor(np.asarray(self.ddim_sigmas, dtype=np.float64)).float()[torch.as_tensor(order)]
             with_noise = bool((sig != 0).any())
             f64b = lambda v: np.asarray(v, dtype=np.float64).tobytes()
-            tkey = (np.asarray(timesteps).tobytes(), f64b(self.ddim_alphas), f64b(self.ddim_alphas_prev), f64b(self.ddim_sigmas))
-            fresh = getattr(st, "_table_key", None) != tkey  # (timestep rows / coefficient table of this plan: upload once)
+            # upload-once caches.  The timestep rows live on the PLAN (one buffer shared by the DDIM / PLMS, guided / unguided
+            # sampler states of that plan), so their key does too; the coefficient table is this state's own
+            rkey = ("ddim", np.asarray(timesteps)[order].astype(np.float32).tobytes())
+            ckey = (f64b(self.ddim_alphas), f64b(self.ddim_alphas_prev), f64b(self.ddim_sigmas))
+            fresh_rows = getattr(plan, "_t_rows_key", None) != rkey
+            fresh_coefs = getattr(st, "_coef_key", None) != ckey
+            fresh = fresh_rows or fresh_coefs
             on_host = any(t is not None and torch.is_tensor(t) and not t.is_cuda for t in (x_T, c_concat, c_cross))
             # uploads from the host never overlap another lane's graph capture (_lib.host_io); a call with everything on
             # the device and an unchanged schedule uploads nothing and takes no lock
@@ -153,11 +158,13 @@ class DDIMSampler(object):
                     plan.load_x_nchw(c_concat, C, plan.cin_pad)
                 require(C + ncat == unet.in_channels, lambda: "latent %d + concat %d != UNet in_channels %d" % ( C, ncat, unet.in_channels), ValueError)
                 plan.load_context(c_cross)
-                if fresh:
+                if fresh_rows:
                     plan.t_rows.copy_(torch.as_tensor(np.asarray(timesteps)[order].astype(np.float32)))
+                    plan._t_rows_key = rkey
+                if fresh_coefs:
                     st.coefs.copy_(ddim_coefficient_table(self.ddim_alphas, self.ddim_alphas_prev, self.ddim_sigmas,
                                                           self.ddim_sqrt_one_minus_alphas, order))
-                    st._table_key = tkey
+                    st._coef_key = ckey
                 # RNG consumption follows the reference: p_sample_ddim draws noise_like(x.shape) in EVERY step, also when
                 # sigma_t == 0 (ddim.py:200, util.py:264-267), so after sample() the device generator has advanced by S
                 # draws of the latent's shape — a caller that seeds once and samples several batches (inference.ipynb)

@@ -28,13 +28,12 @@ from . import knobs as K
 from ._check import require
 from .arch import UNetArch, VAEArch
 from .emitter import Act, Emitter, Program  # noqa: F401  (re-exported: scripts and tests import them from here)
-from .packing import (PW, PWX, PackedUNet, PackedVAEDecoder, PackedVAEEncoder, Packer, _rup, geglu_rows_map,  # noqa: F401
+from .packing import (PW, PackedUNet, PackedVAEDecoder, PackedVAEEncoder, Packer, _rup, geglu_rows_map,  # noqa: F401
                       head_pad, pad_rows_map, qproj_pack)
 from .tuning import TUNE_CACHE, TuneCache  # noqa: F401
-from .xcd_engine import XcdMixin, xcd_gemm_grid  # noqa: F401
 
 
-class UNetPlan(Emitter, XcdMixin):
+class UNetPlan(Emitter):
     """Buffers + programs of one UNet for fixed (B, H, W, n_ctx, rows).
 
     rows = number of timestep-embedding rows: B in 'forward' mode (per-sample t, as
@@ -127,9 +126,6 @@ class UNetPlan(Emitter, XcdMixin):
     def _st(self, P, Lr, x):
         w, v = self.pk.w, self.pk.v
         n = Lr.name
-        out = self.xcd_block(P, Lr, x)
-        if out is not None:
-            return out
         t = n + ".transformer_blocks.0"
         B, HW, M = x.B, x.H * x.W, x.M
         heads, dh = Lr.heads, Lr.dhead

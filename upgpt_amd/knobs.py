@@ -20,13 +20,4 @@ XB_ROWS = int(os.environ.get("UPGPT_XB_ROWS", "0"))  # rows per workgroup (16 / 
 # fused head of a SpatialTransformer (csrc/xblock.hip hblock_kernel: proj_in -> norm1 -> q | k | v, one launch instead of two)
 HBLOCK = os.environ.get("UPGPT_HBLOCK", "auto")
 HBLOCK_GN = os.environ.get("UPGPT_HBLOCK_GN", "1") == "1"  # SpatialTransformer.norm applied on the tile inside that launch
-# per-XCD persistent engine (csrc/xcd.hip, include/upk.h upk_xcd_run_f16): a whole SpatialTransformer as ONE launch, sample b
-# on XCD b % 8, XCD-local barriers (1.04 us measured) between its ten phases.  Built, parity-green and measured in round 5
-# (DESIGN.md 12): inside the replayed forward a block costs 130 us on the engine against 95 us as a launch chain — every
-# phase re-stages its rows through the XCD's shared L2 and pays 2-3 L2 / HBM round trips of 1-2.5 us that a barrier cannot
-# hide — so it is OFF by default: "0" off, "1" wherever the engine takes the shape (any batch: the GPU tests), "auto" =
-# batches that are a multiple of 8 at feature maps of <= XCD_MAXN pixels.  UPGPT_XCD_SPLIT=1: one launch per phase.
-XCD = os.environ.get("UPGPT_XCD", "0")
-XCD_MAXN = int(os.environ.get("UPGPT_XCD_MAXN", "256"))
-XCD_SPLIT = os.environ.get("UPGPT_XCD_SPLIT", "0") == "1"
 LN_LAUNCH_US = 5.0  # what a separate LayerNorm launch costs inside the replayed forward (3.8 us of kernel + its boundary: DESIGN.md 11i / 11j)

@@ -10,10 +10,13 @@ sample() call is still one bs = B batch with the reference's call surface, and a
 the serial path's (tests/test_lanes_gpu.py).  This is the serving shape of the path — independent requests of one
 batch each — not a larger batch: the batch of a UNetModel.forward does not change.
 
-While a pool with more than one lane exists, plans are built with the launch choices tuned for a shared chip
-(tuning.TUNE_CACHE_LANES: chosen by chip time with four chains in flight — few large tiles instead of one small tile per CU),
-and graph captures / plan construction / uploads from pageable host memory are serialised against each other
-(_lib.host_io; a steady-state sample() with its inputs on the device uploads nothing).  DESIGN.md 13.
+Plans built INSIDE a lane of a pool with more than one lane (LanePool.lane(i): the pool's own threads, or a script's main
+thread that enters it) take the launch choices tuned for a shared chip (tuning.TUNE_CACHE_LANES: chosen by chip time with
+four chains in flight — few large tiles instead of one small tile per CU); the switch is scoped to the thread inside the
+lane and part of every plan key (_lib.concurrency), so callers outside the pool keep the single-forward table.  While such a
+pool is alive (until close() / __exit__), graph captures / plan construction / uploads from pageable host memory of ALL
+threads are serialised against each other (_lib.host_io; a steady-state sample() with its inputs on the device uploads
+nothing).  DESIGN.md 13.
 """
 import contextlib
 import os
@@ -43,10 +46,10 @@ class LanePool:
         self.n = int(n)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.gpu = self.device.type == "cuda"
+        self._closed = False
         if self.gpu and self.n > 1:
-            from ._lib import concurrency, set_concurrency
-            set_concurrency(max(concurrency(), self.n))  # (plans built from now on are tuned for a shared chip)
-            from ._lib import get_context
+            from ._lib import _register_pool, get_context
+            _register_pool(self, self.n)  # (host_io() serialises captures against uploads while the pool lives)
             for i in range(self.n):  # every lane's upk_ctx + workspace exists before the first thread starts
                 get_context(self.device, lane=i)
         self.queue_probe = "n/a"
@@ -103,7 +106,7 @@ class LanePool:
 
     def _lane_steps(self, i, stream, fn, K, slots, cond, errors):
         try:
-            with (torch.cuda.device(self.device) if self.gpu else contextlib.nullcontext()), lane(i, stream):
+            with (torch.cuda.device(self.device) if self.gpu else contextlib.nullcontext()), self.lane(i, stream):
                 prev = None
                 if self.gpu:
                     prev = torch.cuda.Event(enable_timing=True)
@@ -124,12 +127,28 @@ class LanePool:
                 errors.append(e)
                 cond.notify_all()
 
+    def lane(self, i, stream=None):
+        """Context manager: the calling thread works in lane `i` of THIS pool — the lane's stream (unless `stream` is given)
+        and plans tuned for self.n batches sharing the chip.  The pool's own threads run in it; a script that builds or
+        replays a lane's plans from its main thread enters it too.  Nothing outside the block changes: a thread that never
+        enters a lane keeps the single-forward launch choices while the pool exists."""
+        require(0 <= int(i) < self.n, "lane index out of range", ValueError)
+        s = stream if stream is not None else self.streams[int(i)]
+        return lane(i, s, concurrency=self.n if (self.gpu and self.n > 1) else 1)
+
     def close(self):
-        """Back to one batch in flight: plans built from now on take the single-forward launch choices again (the lanes'
-        contexts, plans and graphs stay cached for the next pool)."""
-        if self.gpu and self.n > 1:
-            from ._lib import set_concurrency
-            set_concurrency(1)
+        """The pool stops counting as in flight (the lanes' contexts, plans and graphs stay cached for the next pool).
+        Idempotent; also run by __exit__ and __del__."""
+        if not self._closed:
+            self._closed = True
+            from ._lib import _unregister_pool
+            _unregister_pool(self)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def __enter__(self):
         return self

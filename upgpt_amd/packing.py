@@ -1,6 +1,5 @@
 """fp32 master weights (reference key names) -> operands of the kernels, packed once per weight set:
-the implicit-GEMM tile layout of upk_pack_weight_f16 (Packer.pack), the per-XCD engine's fragment layout
-(Packer.pack_xcd), and the PackedUNet / PackedVAE* containers the plans lower against."""
+the implicit-GEMM tile layout of upk_pack_weight_f16 (Packer.pack), and the PackedUNet / PackedVAE* containers the plans lower against."""
 import torch
 
 from . import knobs as K
@@ -23,11 +22,6 @@ def head_pad(d):
 class PW:
     """A packed weight: fp16 tiles + fp32 bias in packed row order."""
     __slots__ = ("w", "n_pad", "bias", "n_out", "k_packed", "ksize", "n_real", "k_real", "ln_colsum", "k_append", "w_phase")
-
-
-class PWX:
-    """A weight packed for the per-XCD engine (Packer.pack_xcd)."""
-    __slots__ = ("w", "bias", "ntiles", "k", "n", "colsum")
 
 
 class Packer:
@@ -137,40 +131,6 @@ class Packer:
 
     def vec(self, name):
         return self.get(name).float().contiguous()
-
-    def pack_xcd(self, w, bias=None, rows=None, cols=None):
-        """[N, K] fp32 -> operands of a upk_xphase GEMM (include/upk.h): fp16 tiles [N/16][K/32][64 lanes][8] (lane
-        16 g + i holds W[16 t + i][32 kc + 8 g .. + 7]) and the fp32 bias in tile order, N padded to 16 and K to 32 with
-        zeros.  rows / cols: index tensors (packed row / column <- source row / column, -1 = zero), applied first."""
-        w = w.float().to(self.dev)
-        if rows is not None:
-            r = torch.as_tensor(rows, device=self.dev).long()
-            wr = w.new_zeros(r.numel(), w.shape[1])
-            wr[r >= 0] = w[r[r >= 0]]
-            if bias is not None:
-                br = w.new_zeros(r.numel())
-                br[r >= 0] = bias.float().to(self.dev)[r[r >= 0]]
-                bias = br
-            w = wr
-        if cols is not None:
-            c = torch.as_tensor(cols, device=self.dev).long()
-            wc = w.new_zeros(w.shape[0], c.numel())
-            wc[:, c >= 0] = w[:, c[c >= 0]]
-            w = wc
-        N, K = w.shape
-        N16, K32 = _rup(N, 16), _rup(K, 32)
-        wp = w.new_zeros(N16, K32)
-        wp[:N, :K] = w
-        T, KC = N16 // 16, K32 // 32
-        px = PWX()
-        px.w = wp.half().view(T, 16, KC, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
-        px.bias = None
-        if bias is not None:
-            px.bias = w.new_zeros(N16)
-            px.bias[:N] = bias.float().to(self.dev)
-        px.ntiles, px.k, px.n = T, K32, N
-        px.colsum = wp.half().float().sum(dim=1).contiguous()  # (of the fp16-rounded rows: folded-LayerNorm GEMMs)
-        return px
 
 
 def qproj_pack(w, gamma, beta, heads, dh, dp, cq, dev):
@@ -283,8 +243,6 @@ class PackedUNet:
                 # transformer's output projection as one GEMM with t2 as an appended K segment (Emitter.fold_ff_out)
                 w[n + ".ff.out+proj_out"] = pk.append_1x1(pk.pack_product(n + ".proj_out", t + ".ff.net.2"),
                                                           w[n + ".proj_out"])
-                if K.XCD != "0" and 32 % heads == 0 and dp in (32, 64, 128) and Lr.ch % 32 == 0:
-                    w[n + ".xcd"] = self._pack_xcd_block(pk, get, n, t, Lr, heads, dh, dp)
             elif Lr.kind == "down":
                 w[n + ".op"] = pk.pack(n + ".op")
             elif Lr.kind == "up":
@@ -292,51 +250,6 @@ class PackedUNet:
         norm("out.0")
         w["out.2"] = pk.pack("out.2")
         self.w, self.v = w, v
-
-
-def _pack_xcd_block(self, pk, get, n, t, Lr, heads, dh, dp):
-    """The seven GEMMs of a SpatialTransformer as per-XCD engine operands (include/upk.h upk_xphase).  Every norm in front
-    of a Linear is folded into it: W' = W * gamma (per input column), b' = b + W beta — SpatialTransformer.norm
-    (attention.py:254) into proj_in, norm1 / norm2 / norm3 (attention.py:212-215) into q|k|v, attn2.to_q and the GEGLU
-    projection; the engine's GroupNorm / LayerNorm then only subtract the mean and scale by rstd."""
-    f = lambda name: get(name).float().to(pk.dev)
-    C_ = Lr.ch
-    inner = 4 * heads * dh
-
-    def folded(wname, gname, bias=None):
-        W = f(wname + ".weight")
-        W = W.reshape(W.shape[0], -1)
-        b = W @ f(gname + ".bias")
-        if bias is not None:
-            b = b + f(bias)
-        return W * f(gname + ".weight")[None, :], b
-
-    o = {}
-    Wi, bi = folded(n + ".proj_in", n + ".norm", n + ".proj_in.bias")
-    o["proj_in"] = pk.pack_xcd(Wi, bi)
-    Wq = torch.cat([f(t + ".attn1.to_q.weight"), f(t + ".attn1.to_k.weight"), f(t + ".attn1.to_v.weight")], 0)
-    g1, b1 = f(t + ".norm1.weight"), f(t + ".norm1.bias")
-    o["qkv"] = pk.pack_xcd(Wq * g1[None, :], Wq @ b1, rows=pad_rows_map(3, heads, dh, dp))
-    hcols = pad_rows_map(1, heads, dh, dp)
-    o["out1"] = pk.pack_xcd(f(t + ".attn1.to_out.0.weight"), f(t + ".attn1.to_out.0.bias"), cols=hcols)
-    W2, b2 = folded(t + ".attn2.to_q", t + ".norm2")
-    o["q2"] = pk.pack_xcd(W2, b2, rows=hcols)
-    o["out2"] = pk.pack_xcd(f(t + ".attn2.to_out.0.weight"), f(t + ".attn2.to_out.0.bias"), cols=hcols)
-    Wg, bg = folded(t + ".ff.net.0.proj", t + ".norm3", t + ".ff.net.0.proj.bias")
-    u = torch.arange(2 * inner)
-    tile, i = u // 16, u % 16
-    grows = torch.where(tile % 2 == 0, (tile // 2) * 16 + i, inner + (tile // 2) * 16 + i)  # tiles alternate value / gate
-    o["geglu"] = pk.pack_xcd(Wg, bg, rows=grows)
-    # proj_out(t2 + ff.net.2(h)) + x = (P F2) h + P t2 + (P b2 + bp) + x: one GEMM over [h | t2]
-    Pw = f(n + ".proj_out.weight")
-    Pw = Pw.reshape(Pw.shape[0], -1)
-    F2, c2 = f(t + ".ff.net.2.weight"), f(t + ".ff.net.2.bias")
-    o["ffout"] = pk.pack_xcd(torch.cat([Pw @ F2, Pw], 1), Pw @ c2 + f(n + ".proj_out.bias"))
-    o["inner"] = inner
-    return o
-
-
-PackedUNet._pack_xcd_block = _pack_xcd_block
 
 
 # ====================================================================== VAE decoder

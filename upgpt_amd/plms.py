@@ -121,8 +121,11 @@ class PLMSSampler(DDIMSampler):
             t_eval = np.concatenate([t_desc[:1], t_desc[min(1, S - 1):min(1, S - 1) + 1], t_desc[1:]])
             require(t_eval.shape[0] == S + 1, "PLMS evaluates S + 1 times", RuntimeError)
             f64b = lambda v: np.asarray(v, dtype=np.float64).tobytes()
-            tkey = (t_eval.tobytes(), f64b(self.ddim_alphas), f64b(self.ddim_alphas_prev), f64b(self.ddim_sigmas))
-            fresh = getattr(st, "_table_key", None) != tkey
+            rkey = ("plms", t_eval.tobytes())  # (the rows belong to the plan, the coefficients to this state: ddim.py)
+            ckey = (f64b(self.ddim_alphas), f64b(self.ddim_alphas_prev), f64b(self.ddim_sigmas))
+            fresh_rows = getattr(plan, "_t_rows_key", None) != rkey
+            fresh_coefs = getattr(st, "_coef_key", None) != ckey
+            fresh = fresh_rows or fresh_coefs
             on_host = any(t is not None and torch.is_tensor(t) and not t.is_cuda for t in (x_T, c_concat, c_cross))
             with (host_io() if (fresh or on_host) else contextlib.nullcontext()):  # (ddim.py _fast_sampling: same rule)
                 img = torch.randn(shape, device=dev) if x_T is None else x_T.to(dev, torch.float32)
@@ -132,11 +135,13 @@ class PLMSSampler(DDIMSampler):
                     plan.load_x_nchw(c_concat, C, plan.cin_pad)
                 require(C + (0 if c_concat is None else c_concat.shape[1]) == unet.in_channels, "latent + concat channels != UNet in_channels", ValueError)
                 plan.load_context(c_cross)
-                if fresh:
+                if fresh_rows:
                     plan.t_rows.copy_(torch.as_tensor(t_eval))
+                    plan._t_rows_key = rkey
+                if fresh_coefs:
                     st.coefs[:S].copy_(ddim_coefficient_table(self.ddim_alphas, self.ddim_alphas_prev, self.ddim_sigmas,
                                                               self.ddim_sqrt_one_minus_alphas, order))
-                    st._table_key = tkey
+                    st._coef_key = ckey
                 for _ in range(S + 1):  # the reference draws (and, eta being 0, discards) one noise tensor per update:
                     torch.randn(shape, device=dev)  # plms.py get_x_prev_and_pred_x0 — same generator state afterwards
                 plan.step.zero_()

@@ -11,20 +11,11 @@ import torch
 
 
 def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
-    if schedule == "linear":
-        betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2
-    elif schedule == "cosine":
-        ts = torch.arange(n_timestep + 1, dtype=torch.float64) / n_timestep + cosine_s
-        alphas = torch.cos(ts / (1 + cosine_s) * np.pi / 2).pow(2)
-        alphas = alphas / alphas[0]
-        betas = torch.clamp(1 - alphas[1:] / alphas[:-1], min=0, max=0.999)
-    elif schedule == "sqrt_linear":
-        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64)
-    elif schedule == "sqrt":
-        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64) ** 0.5
-    else:
-        raise ValueError(f"schedule '{schedule}' unknown.")
-    return betas.numpy()
+    """Only "linear" — what bbox.yaml, the upscale config and every checkpoint of the path use (ddpm.py:85 default).  The
+    reference's cosine / sqrt_linear / sqrt variants (util.py:29-40) serve no config on the path and are refused loudly."""
+    if schedule != "linear":
+        raise NotImplementedError("beta schedule %r is not on the UPGPT inference path (only 'linear' is)" % (schedule,))
+    return (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2).numpy()
 
 
 def make_ddim_timesteps(ddim_discr_method, num_ddim_timesteps, num_ddpm_timesteps, verbose=True):
@@ -37,7 +28,7 @@ def make_ddim_timesteps(ddim_discr_method, num_ddim_timesteps, num_ddpm_timestep
         raise NotImplementedError(f'There is no ddim discretization method called "{ddim_discr_method}"')
     steps = steps + 1  # the +1 gets the final alpha values right (util.py:56-57)
     if verbose:
-        print(f"Selected timesteps for ddim sampler: {steps}")
+        print("ddim timesteps:", steps)
     return steps
 
 
@@ -53,9 +44,7 @@ def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta, verbose=True):
     ratio = (1 - alphas).reciprocal().double() * (1 - ap)
     sigmas = eta * torch.sqrt(ratio * (1 - alphas.double() / ap))
     if verbose:
-        print(f"Selected alphas for ddim sampler: a_t: {alphas}; a_(t-1): {alphas_prev}")
-        print(f"For the chosen value of eta, which is {eta}, "
-              f"this results in the following sigma_t schedule for ddim sampler {sigmas}")
+        print("ddim alphas:", alphas, "alphas_prev:", alphas_prev, "sigmas (eta %s):" % eta, sigmas)
     return sigmas, alphas, alphas_prev
 
 

@@ -70,8 +70,13 @@ class UNetModel(ParamTree):
             from ._lib import host_io
             with torch.cuda.device(dev), host_io():
                 pk = PackedUNet(ctx, self.arch, get)
+                # the pack kernels ran on THIS thread's stream; other lanes read the packed weights from theirs
+                torch.cuda.current_stream(dev).synchronize()
             self._packed[tag] = (fp, pk)
-            for k in [k for k in self._plans if k[0] == tag]:
+            stale = [k for k in self._plans if k[0] == tag]
+            if stale:
+                torch.cuda.synchronize(dev)  # (another lane may still be replaying graphs of the old weight set)
+            for k in stale:
                 self._plans.pop(k).close()  # (plans of the old weight set: their captured graphs go with them)
         return ctx, tag, self._packed[tag][1]
 
@@ -125,6 +130,7 @@ class UNetModel(ParamTree):
         with torch.cuda.device(pl.dev):
             pl.load_x_nchw(x, 0, pl.cin_pad)
             pl.t_rows.copy_(timesteps.to(pl.dev, torch.float32))
+            pl._t_rows_key = None  # (a sampler sharing this plan re-uploads its rows)
             pl.load_context(context)
             pl.prep.run()
             pl.body.run()

@@ -97,9 +97,11 @@ class AutoencoderKL(ParamTree):
             params = dict(self.named_parameters())
             with torch.cuda.device(p.device), host_io():
                 self._packed = (fp, PackedVAEDecoder(ctx, self.arch, lambda n: params[n].data))
+                torch.cuda.current_stream(p.device).synchronize()  # (packed on this lane's stream, read from every lane's)
             self._plans = {}
-        from ._lib import current_lane
-        key = (B, h, w, float(scale_factor), current_lane())
+        from ._lib import concurrency, current_lane
+        # (the tuning table the plan is built from is part of its identity, as in UNetModel.plan)
+        key = (B, h, w, float(scale_factor), concurrency() > 1, current_lane())
         if key not in self._plans:
             mine = [k for k in self._plans if k[-1] == key[-1]]
             if len(mine) >= 4:  # (per lane: another lane's plans may be executing)
@@ -136,9 +138,10 @@ class AutoencoderKL(ParamTree):
             params = dict(self.named_parameters())
             with torch.cuda.device(p.device), host_io():
                 self._packed_enc = (fp, PackedVAEEncoder(ctx, self.arch, lambda n: params[n].data))
+                torch.cuda.current_stream(p.device).synchronize()
             self._enc_plans = {}
-        from ._lib import current_lane
-        key = (B, H, W, current_lane())
+        from ._lib import concurrency, current_lane
+        key = (B, H, W, concurrency() > 1, current_lane())
         if key not in self._enc_plans:
             mine = [k for k in self._enc_plans if k[-1] == key[-1]]
             if len(mine) >= 4:
