@@ -497,6 +497,21 @@ long long upk_kernel_launches(upk_ctx* ctx, int reset);
 int upk_advance_step(upk_ctx* ctx, int32_t* step, upk_stream stream);
 
 /* ------------------------------------------------------------------ */
+/* CU-partitioned streams (execution lanes on disjoint CU sets).         */
+/* The reference has no counterpart: it runs one batch on `cuda:0`       */
+/* (app.py:21); lanes are this build's serving mode. */
+/* ------------------------------------------------------------------ */
+/* Creates a stream whose kernels are only placed on the CUs whose bit is set in `mask` (nwords 32-bit words, bit b of
+ * word w = CU-mask bit 32 w + b of the HSA queue; how bits map to XCDs is measured with upk_probe_placement, not
+ * assumed).  The caller owns the stream (upk_stream_destroy).  Never synchronises. */
+int upk_stream_create_cumask(upk_ctx* ctx, const uint32_t* mask, int nwords, upk_stream* out);
+int upk_stream_destroy(upk_ctx* ctx, upk_stream stream);
+/* Launches `nblocks` one-wave workgroups on `stream`; workgroup i writes {HW_REG_XCC_ID, HW_REG_HW_ID} to
+ * out_dev[2 i], out_dev[2 i + 1] (device memory, 8 nblocks bytes) and holds its CU for ~spin_cycles shader clocks so that
+ * the grid spreads over every CU the stream may use.  Graph-capturable. */
+int upk_probe_placement(upk_ctx* ctx, uint32_t* out_dev, int nblocks, int spin_cycles, upk_stream stream);
+
+/* ------------------------------------------------------------------ */
 /* HIP graph helpers (the 50-step loop replays one captured step).      */
 /* ------------------------------------------------------------------ */
 typedef struct upk_graph upk_graph;

@@ -530,6 +530,42 @@ extern "C" int upk_advance_step(upk_ctx* ctx, int32_t* step, upk_stream stream_)
   return upk_check_launch(ctx, "advance_step");
 }
 
+// ------------------------------------------------------------------ CU-partitioned streams
+// A stream whose kernels may only be placed on the CUs of `mask` (hipExtStreamCreateWithCUMask -> the HSA queue's CU
+// mask).  upk_probe_placement records where the workgroups of a launch on `stream` actually ran, which is how the host
+// (upgpt_amd/lanes.py cu_partitions) learns the mask-bit -> XCD mapping instead of assuming one.
+__global__ void probe_placement_kernel(uint32_t* out, int spin) {
+  if (threadIdx.x == 0) {
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    out[blockIdx.x * 2] = xcc;
+    out[blockIdx.x * 2 + 1] = hw;
+    const long long t0 = __builtin_readcyclecounter();  // hold the CU for a moment so that the grid spreads over the mask
+    while (__builtin_readcyclecounter() - t0 < spin) __builtin_amdgcn_s_sleep(8);
+  }
+}
+
+extern "C" int upk_stream_create_cumask(upk_ctx* ctx, const uint32_t* mask, int nwords, upk_stream* out) {
+  if (!ctx || !mask || nwords <= 0 || !out) return upk_fail(ctx, UPK_EINVAL, "upk_stream_create_cumask: bad argument");
+  hipStream_t s = nullptr;
+  UPK_HIP(ctx, hipExtStreamCreateWithCUMask(&s, (uint32_t)nwords, mask));
+  *out = (upk_stream)s;
+  return UPK_OK;
+}
+
+extern "C" int upk_stream_destroy(upk_ctx* ctx, upk_stream stream) {
+  if (!ctx || !stream) return upk_fail(ctx, UPK_EINVAL, "upk_stream_destroy: bad argument");
+  UPK_HIP(ctx, hipStreamDestroy((hipStream_t)stream));
+  return UPK_OK;
+}
+
+extern "C" int upk_probe_placement(upk_ctx* ctx, uint32_t* out_dev, int nblocks, int spin_cycles, upk_stream stream) {
+  if (!ctx || !out_dev || nblocks <= 0) return upk_fail(ctx, UPK_EINVAL, "upk_probe_placement: bad argument");
+  hipLaunchKernelGGL(probe_placement_kernel, dim3(nblocks), dim3(64), 0, (hipStream_t)stream, out_dev, spin_cycles);
+  return upk_check_launch(ctx, "probe_placement");
+}
+
 // ------------------------------------------------------------------ HIP graphs
 struct upk_graph {
   hipGraph_t graph;
