@@ -611,7 +611,8 @@ def main():
                     help="also time BASELINE configs[2] end to end: CLIP text tower (8 prompts) + CLIP ViT-L/14 image tower "
                          "(8 x 9 style crops) + SMPL projection -> 50-step DDIM -> decode")
     ap.add_argument("--upscale", action="store_true",
-                    help="also time BASELINE configs[4]: the upscale UNet, bs=4, 64x64 latent, 50-step DDIM (UNet loop only)")
+                    help="also time BASELINE configs[4]: the upscale UNet, bs=4, 50-step DDIM (UNet loop only), at the 64x64 latent "
+                         "BASELINE words and at the 128x96 latent its own config states")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -801,6 +802,10 @@ def main():
             result["config_full_cond_with_encoders"] = encoders_secondary(model, wl, dev, sec_pool)
         if args.upscale and world == 1:
             result["config_upscale_bs4_64x64"] = upscale_secondary(args.ddim_steps, dev, pool=sec_pool)
+            # the same model at the size its own config states (models/upgpt/upscale/config.yaml:14-16: image_size [128, 96],
+            # channels 3): BASELINE configs[4] config-true, 3869.7 GF per forward
+            result["config_upscale_config_true"] = dict(upscale_secondary(args.ddim_steps, dev, hw=(128, 96), pool=sec_pool),
+                                                        latent="3x128x96", batch=4)
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(hw, args.ddim_steps, args.batch)
         print(json.dumps(result), flush=True)

@@ -132,6 +132,45 @@ if MODE == "cumask":
     for label, n, a, b in rows:
         print("%-58s %5d %12.3f %12.3f %10.1f" % (label, n, a, b, 8 / (b * 50) * 1e3))
 
+elif MODE == "maskdiag":
+    # what does a CU mask do on this box?  For a few masks: XCDs and CUs the probe kernel's workgroups land on
+    import collections
+    ctx0 = L.get_context(0, lane=0)
+
+    def words(bits):
+        w = [0] * 8
+        for b in bits:
+            w[b // 32] |= 1 << (b % 32)
+        return w
+
+    def hist(stream, nblocks=4096, spin=60000):
+        out = torch.zeros(nblocks * 2, dtype=torch.int32, device="cuda")
+        ctx0._chk(ctx0.lib.upk_probe_placement(ctx0.h, out.data_ptr(), nblocks, spin, C.c_void_p(stream.cuda_stream)))
+        torch.cuda.synchronize()
+        v = out.cpu().view(nblocks, 2)
+        h = collections.defaultdict(set)
+        for x, hw in zip((v[:, 0] & 0xF).tolist(), ((v[:, 1] >> 8) & 0xFF).tolist()):
+            h[x].add(hw)
+        return {x: len(c) for x, c in sorted(h.items())}
+
+    print("unmasked torch stream:", hist(torch.cuda.Stream()), flush=True)
+    cases = [("bit 0", [0]), ("bits 0-7", range(8)), ("bits 0-31", range(32)), ("bits 0-63", range(64)), ("bits 0-127", range(128)),
+             ("bits 128-255", range(128, 256)), ("every 8th bit (b % 8 == 0)", range(0, 256, 8)), ("b % 8 in {0,1}", [b for b in range(256) if b % 8 < 2]),
+             ("b % 16 < 2", [b for b in range(256) if b % 16 < 2]), ("all 256", range(256)), ("bits 32-63", range(32, 64)), ("bits 224-255", range(224, 256))]
+    for nwords in (8, 10):
+        for name, bits in cases:
+            w = words(bits) + [0] * (nwords - 8)
+            arr = (C.c_uint32 * len(w))(*w)
+            h = C.c_void_p()
+            rc = ctx0.lib.upk_stream_create_cumask(ctx0.h, arr, len(w), C.byref(h))
+            if rc != 0:
+                print("%d words, %-28s: create failed: %s" % (nwords, name, (ctx0.lib.upk_last_error(ctx0.h) or b"").decode()), flush=True)
+                continue
+            s = torch.cuda.ExternalStream(h.value)
+            hh = hist(s)
+            print("%d words, %-28s: %d CUs on XCDs %s" % (nwords, name, sum(hh.values()), hh), flush=True)
+            ctx0.lib.upk_stream_destroy(ctx0.h, C.c_void_p(s.cuda_stream))
+
 elif MODE == "align":
     pool = LanePool(4)
     streams = list(pool.streams)
@@ -169,7 +208,7 @@ elif MODE == "controls":
     rows = []
     for lanes, B in ((1, 8), (1, 16), (1, 32), (2, 16), (4, 8), (4, 16), (2, 32)):
         pool = LanePool(lanes) if lanes > 1 else None
-        streams = list(pool.streams) if pool else [torch.cuda.current_stream()]
+        streams = list(pool.streams) if pool else [torch.cuda.Stream()]  # (the legacy stream cannot be captured)
         for conc in ((1, 4) if lanes == 1 else (lanes,)):  # one chain: both tables (the shared-chip one has the big tiles)
             t0 = time.time()
             plans = [lane_plan(i, s, conc, B) for i, s in enumerate(streams)]

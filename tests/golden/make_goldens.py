@@ -2,7 +2,7 @@
 """Generates the golden fixtures under tests/golden/ by running the REAL reference
 (/root/reference, pure Python, imported read-only) on CPU in the build container.
 
-    python tests/golden/make_goldens.py [--only tiny|bbox|upscale|schedule|encode|plms|extra|a15|upscale64]
+    python tests/golden/make_goldens.py [--only tiny|bbox|upscale|schedule|encode|plms|extra|a15|upscale64|upscale_true]
 
 The reference never travels: only its OUTPUTS (small arrays) and state-dict key/shape
 manifests are committed.  Weights and inputs are regenerated from upgpt_amd/synth.py's
@@ -430,6 +430,24 @@ def gen_upscale64(out):
     print("upscale64 ->", out, z.shape)
 
 
+def gen_upscale_true(out):
+    """BASELINE.json configs[4] at the size the reference's own config states (models/upgpt/upscale/config.yaml:14-16:
+    image_size [128, 96], channels 3): upscale model, latent 3 x 128 x 96, 50-step DDIM, eta 0 — one B = 1 reference run
+    (the GPU test runs it at B = 1 and as sample 0 of the B = 4 batch BASELINE names), plus the first UNet evaluation."""
+    model, params = build_reference("upscale")
+    inp = synth.synth_inputs(1, (128, 96), 3, 86, 768, seed=41, concat_channels=3)
+    cond = {"c_crossattn": inp["c_crossattn"], "c_concat": [inp["c_concat"]]}
+    g = {"unet_eps": model.apply_model(inp["x_T"], torch.tensor([981]), cond).numpy()}
+    ref_ddim.noise_like = NoiseFeed(None)
+    z, _ = ref_ddim.DDIMSampler(model).sample(S=50, batch_size=1, shape=(3, 128, 96), conditioning=cond, eta=0.0,
+                                              x_T=inp["x_T"].clone(), verbose=False)
+    g["ddim_S50/z"] = z.numpy()
+    g["crc_inputs"] = np.asarray([synth.crc_of(inp["x_T"]), synth.crc_of(inp["c_crossattn"]), synth.crc_of(inp["c_concat"])],
+                                 dtype=np.uint64)
+    np.savez_compressed(out, **g)
+    print("upscale_true ->", out, z.shape)
+
+
 def gen_schedule(out):
     g = {}
     for name, (ls, le) in {"bbox": (0.00085, 0.012), "upscale": (0.0001, 0.02)}.items():
@@ -460,12 +478,14 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    kinds = [a.only] if a.only else ["schedule", "tiny", "bbox", "upscale", "encode", "plms", "extra", "a15", "upscale64"]
+    kinds = [a.only] if a.only else ["schedule", "tiny", "bbox", "upscale", "encode", "plms", "extra", "a15", "upscale64", "upscale_true"]
     for k in kinds:
         if k == "a15":
             gen_a15(os.path.join(HERE, "a15.npz"))
         elif k == "upscale64":
             gen_upscale64(os.path.join(HERE, "upscale64.npz"))
+        elif k == "upscale_true":
+            gen_upscale_true(os.path.join(HERE, "upscale_true.npz"))
         elif k == "extra":
             gen_extra(os.path.join(HERE, "extra.npz"))
         elif k == "plms":

@@ -676,6 +676,51 @@ def test_upscale_64x64_b4_fifty_steps_vs_reference_golden():
     assert mse(za[:1], g["ddim_S50/z"]) < 1e-3
 
 
+def test_upscale_config_true_128x96_b4_fifty_steps_vs_reference_golden():
+    """BASELINE.json configs[4] at the size the reference's config states (models/upgpt/upscale/config.yaml:14-16: latent
+    3 x 128 x 96), bs 4, 50-step DDIM end to end: sample 0 against the reference's own B = 1 run
+    (tests/golden/upscale_true.npz, written by make_goldens.py --only upscale_true from the imported reference), bitwise
+    determinism of the B = 4 batch, and batch independence (sample 0 of the batch == the B = 1 run up to launch-shape
+    rounding)."""
+    g = np.load(os.path.join(G, "upscale_true.npz"))
+    model, sd = get_model("upscale")
+    k = KIND["upscale"]
+    one = synth.synth_inputs(1, (128, 96), k["C"], k["ntok"], 768, seed=41, concat_channels=k["cc"])
+    assert [synth.crc_of(one[n]) for n in ("x_T", "c_crossattn", "c_concat")] == [int(v) for v in g["crc_inputs"]]
+    inp = synth.synth_inputs(4, (128, 96), k["C"], k["ntok"], 768, seed=42, concat_channels=k["cc"])
+    for n in ("x_T", "c_crossattn", "c_concat"):  # sample 0 of the batch = the reference's B = 1 sample
+        inp[n] = torch.cat([one[n], inp[n][1:]], 0)
+    cond1 = {"c_crossattn": inp["c_crossattn"][:1].cuda(), "c_concat": [inp["c_concat"][:1].cuda()]}
+    eps = model.apply_model(inp["x_T"][:1].cuda(), torch.tensor([981]).cuda(), cond1)
+    assert mse(eps, g["unet_eps"]) < 1e-4
+    run = lambda c, x, b: DDIMSampler(model).sample(50, b, (k["C"], 128, 96), c, eta=0.0, x_T=x, verbose=False)[0]
+    z1 = run(cond1, inp["x_T"][:1].cuda(), 1)
+    assert mse(z1, g["ddim_S50/z"]) < 1e-3
+    cond = {"c_crossattn": inp["c_crossattn"].cuda(), "c_concat": [inp["c_concat"].cuda()]}
+    za, zb = run(cond, inp["x_T"].cuda(), 4), run(cond, inp["x_T"].cuda(), 4)
+    assert torch.equal(za, zb) and torch.isfinite(za).all()
+    assert mse(za[:1], g["ddim_S50/z"]) < 1e-3
+    assert mse(za[:1], z1) < 1e-3  # no cross-sample op anywhere on the path (SURVEY.md 8e); tiles differ between B = 1 and 4
+
+
+def test_ddim_and_plms_sharing_one_plan_keep_their_own_timestep_rows():
+    """DDIM with S + 1 steps and PLMS with S steps get the SAME UNetPlan (rows = S + 1) and therefore one t_rows buffer:
+    DDIM(11) -> PLMS(10) -> DDIM(11) must re-upload the DDIM rows for the third call (the upload-once key used
+    to live on the per-sampler state and left PLMS's evaluation timesteps in place — silently wrong samples)."""
+    from upgpt_amd.plms import PLMSSampler
+    model, _ = get_model("tiny")
+    inp = inputs("tiny", 2)
+    cond = {"c_crossattn": inp["c_crossattn"].cuda(), "c_concat": [inp["c_concat"].cuda()]}
+    x_T = inp["x_T"].cuda()
+    ddim, plms = DDIMSampler(model), PLMSSampler(model)
+    a = ddim.sample(11, 2, (4, 32, 24), cond, eta=0.0, x_T=x_T, verbose=False)[0]
+    p1 = plms.sample(10, 2, (4, 32, 24), cond, eta=0.0, x_T=x_T, verbose=False)[0]
+    b = ddim.sample(11, 2, (4, 32, 24), cond, eta=0.0, x_T=x_T, verbose=False)[0]
+    p2 = plms.sample(10, 2, (4, 32, 24), cond, eta=0.0, x_T=x_T, verbose=False)[0]
+    assert torch.equal(a, b), "DDIM after PLMS on the shared plan differs from DDIM before it"
+    assert torch.equal(p1, p2) and not torch.equal(a, p1)
+
+
 def test_sampler_advances_the_generator_like_the_reference():
     """The reference draws noise_like(x.shape) in every step, also for sigma = 0 (ddim.py:200): after sample() the
     device generator has advanced by one draw for x_T plus S draws of the latent's shape (PLMS: S + 1)."""
