@@ -426,6 +426,32 @@ def igemm_traffic_bytes_per_launch():
         return None, None, None
 
 
+LANES_TRAFFIC_FILE = "profiles/r06_lanes_traffic.json"   # scripts/lanes_pmc_summary.py over scripts/lanes_replay.py (PMC passes)
+LANES_TRACE_FILE = "profiles/r06_lanes_bench_trace.json"  # scripts/trace_frac.py over the kernel trace of this bench command
+
+
+def _built_sources_hash():
+    try:
+        with open(os.path.join(ROOT, "upgpt_amd", "libupk.so.sha256")) as fh:
+            return fh.read().strip()
+    except OSError:
+        return None
+
+
+def committed_summary(rel):
+    """A summary a profiler session committed under profiles/ (rocprofv3 cannot run inside this process), or (None, why).
+    It is only reported when it names the kernel sources of THIS build (SHA-256 over csrc/ + upk.h, libupk.so.sha256)."""
+    try:
+        with open(os.path.join(ROOT, rel)) as fh:
+            d = json.load(fh)
+    except Exception:
+        return None, "%s: not collected" % rel
+    if d.get("kernel_sources_sha256") != _built_sources_hash():
+        return None, "STALE, not reported: %s was collected for kernel sources %s (commit %s), this build is %s" % (
+            rel, str(d.get("kernel_sources_sha256"))[:12], d.get("commit", "?"), str(_built_sources_hash())[:12])
+    return d, "%s (%s; commit %s)" % (rel, d.get("command", "rocprofv3"), d.get("commit", "?"))
+
+
 def unet_forward_ms(model, wl, reps=20):
     """Graph-replayed UNet forward + DDIM update (one sampler step), ms."""
     unet = model.model.diffusion_model
@@ -712,14 +738,15 @@ def main():
         t_model, f_model, b_model = arch.unet_layer_roofline(a, args.batch, hw[0], hw[1], 87, PEAK_MFMA_F16_TFLOPS * 1e12,
                                                              PEAK_HBM_TBS * 1e12)
         n_api, n_k = prof["igemm"]["launches_per_fwd"], prof["igemm"]["kernels_per_fwd"]
-        result["roofline"] = {
+        kernel_desc = ("igemm_ws_kernel<*> + igemm_kernel<*> + igemm_as_kernel<*> + igemm_bt_kernel<*> + mlp_kernel<*> + hblock_kernel<*> + "
+                       "xblock_kernel<*> + igemm_reduce[_gn|_gnapply]_kernel "
+                       "(implicit-GEMM conv / Linear in every tile configuration, the A-stationary Linears, the fused "
+                       "row-chain kernels of the 32x32-level transformer blocks (head, cross-attention half, feed-forward "
+                       "tail), with the split-K reduce passes and the GroupNorm work they carry)")
+        # ---- ONE forward with the chip to itself (the configuration of rounds 1-4; `serial` when lanes are in flight)
+        single = {
             "bound": "mfma",
-            "kernel": "igemm_ws_kernel<*> + igemm_kernel<*> + igemm_as_kernel<*> + mlp_kernel<*> + hblock_kernel<*> + "
-                      "xblock_kernel<*> + igemm_reduce[_gn|_gnapply]_kernel "
-                      "(implicit-GEMM conv / Linear in every tile configuration, the A-stationary Linears, the fused "
-                      "row-chain kernels of the 32x32-level transformer blocks (head, cross-attention half, feed-forward "
-                      "tail), with the split-K reduce passes and the GroupNorm work they carry): %d conv/GEMM "
-                      "launches = %d kernels per UNet forward" % (n_api, n_k),
+            "kernel": kernel_desc + ": %d conv/GEMM launches = %d kernels per UNet forward" % (n_api, n_k),
             "method": "graph-replay difference: (forward) - (forward without the class), HIP events on the launch stream; "
                       "GroupNorm / LayerNorm work done inside a conv/GEMM launch (split-K reduce pass that normalises, "
                       "folded LayerNorm, statistics by-products) is timed with this class, not with the norm classes",
@@ -737,28 +764,58 @@ def main():
             "layer_model_ms": t_model * 1e3, "layer_model_bytes_per_fwd": b_model,
             "frac_layer": t_model * 1e3 / fwd_ms,
         }
-        if lanes_prof is not None:
-            # the timed configuration: the class's chip time per forward with n_lanes forwards in flight
+        dk = single["dominant_kernel"]
+        if dom_l2 and dk and dk.get("us_per_launch_in_situ"):
+            single["l2_bytes_per_launch"] = dom_l2["bytes_per_launch"]
+            single["l2_frac"] = dom_l2["bytes_per_launch"] / (dk["us_per_launch_in_situ"] * 1e-6) / (PEAK_L2_TBS * 1e12)
+            single["l2_kernel"] = dom_l2["kernel"]
+            single["l2_hit_rate"] = dom_l2["hit_rate"]
+        if lanes_prof is None:
+            result["roofline"] = single
+        else:
+            # ---- the TIMED configuration: n_lanes forwards in flight on the shared-chip table.  Every top-level figure of
+            # the block describes it; the single-forward figures live under `serial` and nowhere else.
             fwd_l, cls_l, dom_l = lanes_prof
-            ser = {k: result["roofline"][k] for k in ("achieved", "frac", "avg_launch_us", "avg_kernel_us", "frac_layer", "method")}
             ach_l = ig_flops / (cls_l["igemm"] * 1e-3) / 1e12
-            result["roofline"].update({
-                "achieved": ach_l, "frac": ach_l / PEAK_MFMA_F16_TFLOPS,
-                "avg_launch_us": cls_l["igemm"] * 1e3 / max(1, n_api), "avg_kernel_us": cls_l["igemm"] * 1e3 / max(1, n_k),
-                "frac_layer": t_model * 1e3 / fwd_l,
+            pmc, pmc_src = committed_summary(LANES_TRAFFIC_FILE)
+            trc, trc_src = committed_summary(LANES_TRACE_FILE)
+            lanes_launches = (pmc or {}).get("conv_gemm_launches_per_forward") or n_api
+            blk = {
+                "bound": "mfma",
+                "kernel": kernel_desc + ", launch choices of the shared-chip table (tuned_gfx950_lanes.json)",
                 "method": "%d forwards in flight (the timed configuration): every lane's captured forward replayed concurrently on "
                           "its own hardware queue, in full and without the class in every lane; (wall time per forward) - (same "
-                          "without the class) = the class's chip time per forward.  `serial` holds the same class for ONE "
-                          "forward with the chip to itself (graph-replay difference, HIP events), as in rounds 1-4; "
-                          "top_kernel / dominant_kernel / l2_* are single-forward figures as well" % n_lanes,
+                          "without the class) = the class's chip time per forward (HIP-event / host clock around the replays; a "
+                          "profiler's per-kernel durations overlap here).  frac_from_trace recomputes the whole-job figure from the "
+                          "committed rocprofv3 kernel trace; traffic / l2_* / mfma_busy are PMC passes over the same replay "
+                          "(scripts/lanes_replay.py).  `serial` = ONE forward with the chip to itself, as in rounds 1-4" % n_lanes,
+                "achieved": ach_l, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s", "frac": ach_l / PEAK_MFMA_F16_TFLOPS,
                 "forwards_in_flight": n_lanes, "fwd_ms_per_forward_in_flight": fwd_l,
-                "class_ms_per_fwd_in_flight": cls_l, "dominant_kernel_in_flight": dom_l, "serial": ser})
-        dk = result["roofline"]["dominant_kernel"]
-        if dom_l2 and dk and dk.get("us_per_launch_in_situ"):
-            result["roofline"]["l2_bytes_per_launch"] = dom_l2["bytes_per_launch"]
-            result["roofline"]["l2_frac"] = dom_l2["bytes_per_launch"] / (dk["us_per_launch_in_situ"] * 1e-6) / (PEAK_L2_TBS * 1e12)
-            result["roofline"]["l2_kernel"] = dom_l2["kernel"]
-            result["roofline"]["l2_hit_rate"] = dom_l2["hit_rate"]
+                "class_ms_per_fwd_in_flight": cls_l, "dominant_kernel": dom_l,
+                "algorithmic_flops_per_fwd": ig_flops, "launches_per_fwd": lanes_launches,
+                "avg_launch_us": cls_l["igemm"] * 1e3 / max(1, lanes_launches),
+                "layer_model_ms": t_model * 1e3, "layer_model_bytes_per_fwd": b_model, "frac_layer": t_model * 1e3 / fwd_l,
+                # PMC, four forwards in flight: fabric bytes (FETCH_SIZE x2 + WRITE_SIZE) per conv/GEMM launch of a lane-forward
+                "traffic": None, "traffic_source": pmc_src,
+                "frac_from_trace": None, "frac_from_trace_source": trc_src,
+                "serial": single,
+            }
+            if pmc:
+                cls_b = pmc.get("per_lane_forward_conv_gemm_class", {})
+                if "FETCH_SIZE" in cls_b:
+                    blk["traffic"] = (cls_b["FETCH_SIZE"] + cls_b.get("WRITE_SIZE", 0.0)) / max(1, lanes_launches)
+                blk["fabric_bytes_per_lane_forward"] = pmc.get("fabric_bytes_per_lane_forward")
+                blk["fabric_bytes_per_forward_one_lane_same_table"] = pmc.get("control_one_lane_same_table_fabric_bytes_per_forward")
+                blk["l2_bytes_per_lane_forward"] = (pmc.get("l2_requests_per_lane_forward") or 0) * 128.0 or None
+                blk["l2_hit_rate"] = pmc.get("l2_hit_rate")
+                blk["mfma_busy_over_gui_active"] = pmc.get("mfma_busy_over_gui_active")
+                blk["dominant_kernel_pmc"] = pmc.get("dominant_kernel")
+                blk["pmc_dispatch_overlap"] = pmc.get("dispatch_overlap_under_pmc")
+            if trc:
+                blk["frac_from_trace"] = trc.get("frac_from_trace")
+                blk["trace_union_ms_per_forward"] = trc.get("union_ms_per_forward")
+                blk["trace_kernels_running_while_busy"] = trc.get("kernels_running_while_busy")
+            result["roofline"] = blk
         result["unet"] = {"fwd_ms_graph": fwd_ms, "body_ms_graph": body_ms, "algorithmic_gflop_per_fwd": flops_fwd / 1e9,
                           "mfma_util": flops_fwd / (fwd_ms * 1e-3) / (PEAK_MFMA_F16_TFLOPS * 1e12),
                           "kernel_launches_per_fwd": n_kernels,

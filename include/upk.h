@@ -510,6 +510,10 @@ int upk_stream_destroy(upk_ctx* ctx, upk_stream stream);
  * out_dev[2 i], out_dev[2 i + 1] (device memory, 8 nblocks bytes) and holds its CU for ~spin_cycles shader clocks so that
  * the grid spreads over every CU the stream may use.  Graph-capturable. */
 int upk_probe_placement(upk_ctx* ctx, uint32_t* out_dev, int nblocks, int spin_cycles, upk_stream stream);
+/* One wave spins for ~spin_wall_ticks ticks of the constant 100 MHz wall clock and writes {shader-clock cycles elapsed,
+ * wall ticks elapsed} to out_dev[0..1] (two uint64): shader MHz = 100 * out[0] / out[1] — the clock the chip sustains under
+ * whatever else is running (bench.py reports it for the timed configuration). */
+int upk_probe_clock(upk_ctx* ctx, unsigned long long* out_dev, long long spin_wall_ticks, upk_stream stream);
 
 /* ------------------------------------------------------------------ */
 /* HIP graph helpers (the 50-step loop replays one captured step).      */

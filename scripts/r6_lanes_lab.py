@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import upgpt_amd
 from upgpt_amd import _lib as L
 from upgpt_amd import synth
-from upgpt_amd.lanes import LanePool, cu_partition_streams, probe_placement
+from upgpt_amd.lanes import LanePool, cu_partition_streams
 
 MODE = sys.argv[1] if len(sys.argv) > 1 else "cumask"
 REPS = int(os.environ.get("LAB_REPS", "8"))
@@ -96,7 +96,10 @@ def graph_probe(ctx, s, nblocks=1024):
     torch.cuda.synchronize()
     ctx.graph_destroy(g)
     v = out.cpu().view(nblocks, 2)
-    return sorted(set((v[:, 0] & 0xF).tolist()))
+    seen = {}
+    for x, cu in zip((v[:, 0] & 0xF).tolist(), ((v[:, 1] >> 8) & 0xFF).tolist()):
+        seen.setdefault(x, set()).add(cu)
+    return {x: len(c) for x, c in sorted(seen.items())}
 
 
 if MODE == "cumask":
@@ -115,15 +118,15 @@ if MODE == "cumask":
 
     run("shared chip (256 CUs), latency table", list(pool.streams), 1)
     run("shared chip (256 CUs), shared-chip table", list(pool.streams), 4)
-    for parts, tag in (([(0, 1), (2, 3), (4, 5), (6, 7)], "4 x 2 XCDs (64 CUs)"), ([(0, 1, 2, 3), (4, 5, 6, 7)], "2 x 4 XCDs (128 CUs)"),
-                       ([(i,) for i in range(8)], "8 x 1 XCD (32 CUs)"), ([(0, 2), (1, 3), (4, 6), (5, 7)], "4 x 2 XCDs, non-adjacent pairs")):
+    for n in (4, 2, 8):
+        tag = "%d x %d CUs (CU slots, every XCD)" % (n, 256 // n)
         try:
-            streams, scheme, seen = cu_partition_streams(ctx0, parts)
+            streams, seen = cu_partition_streams(ctx0, n)
         except Exception as e:
             print("%s: %s" % (tag, e), flush=True)
             continue
-        print("%s: mask scheme %s; probe saw %s" % (tag, scheme, [(sorted(x), n) for x, n in seen]), flush=True)
-        print("  inside a captured graph the probe saw XCDs:", [graph_probe(ctx0, s) for s in streams[:2]], flush=True)
+        print("%s: probe placement per stream %s" % (tag, seen), flush=True)
+        print("  inside a captured graph the probe of stream 0 saw XCDs:", graph_probe(ctx0, streams[0]), flush=True)
         ov = [pool._overlap(streams[0], s, 200000)[0] for s in streams[1:]]
         print("  stream 0 overlaps with the others (distinct hardware queues):", ov, flush=True)
         run(tag + ", latency table", streams, 1)
@@ -170,6 +173,28 @@ elif MODE == "maskdiag":
             hh = hist(s)
             print("%d words, %-28s: %d CUs on XCDs %s" % (nwords, name, sum(hh.values()), hh), flush=True)
             ctx0.lib.upk_stream_destroy(ctx0.h, C.c_void_p(s.cuda_stream))
+
+elif MODE == "clock":
+    # shader clock under load: a spinning probe wave on a fifth stream while 0 / 1 / 4 lanes replay forwards
+    pool = LanePool(4)
+    streams = list(pool.streams)
+    plans = [lane_plan(i, s, 4) for i, s in enumerate(streams)]
+    gs = [capture(p, s) for p, s in zip(plans, streams)]
+    ctx0 = L.get_context(0, lane=0)
+    ps = torch.cuda.Stream()
+    out = torch.zeros(2, dtype=torch.int64, device="cuda")
+    for nl in (0, 1, 4, 4):
+        torch.cuda.synchronize()
+        for r in range(40 if nl else 0):  # ~60 ms of lanes work per probe
+            for p, g, s in list(zip(plans, gs, streams))[:nl]:
+                p.ctx._chk(p.lib.upk_graph_launch(p.hctx, g, s.cuda_stream))
+            if r == 8:
+                ctx0._chk(ctx0.lib.upk_probe_clock(ctx0.h, out.data_ptr(), 2_000_000, C.c_void_p(ps.cuda_stream)))  # 20 ms
+        if not nl:
+            ctx0._chk(ctx0.lib.upk_probe_clock(ctx0.h, out.data_ptr(), 2_000_000, C.c_void_p(ps.cuda_stream)))
+        torch.cuda.synchronize()
+        c, w = out.tolist()
+        print("%d lanes replaying: shader clock %.0f MHz over %.1f ms (cycles %d, 100 MHz ticks %d)" % (nl, 100.0 * c / max(1, w), w / 1e5, c, w), flush=True)
 
 elif MODE == "align":
     pool = LanePool(4)

@@ -29,7 +29,7 @@ SYMBOLS = [
     "upk_patchify_nchw_f32_f16", "upk_vit_assemble_f16", "upk_gather_rows_f16",
     "upk_advance_step", "upk_step_autoadvance", "upk_kernel_launches", "upk_graph_begin", "upk_graph_end", "upk_graph_launch", "upk_graph_destroy",
     "upk_prof_enable", "upk_prof_collect",
-    "upk_stream_create_cumask", "upk_stream_destroy", "upk_probe_placement",
+    "upk_stream_create_cumask", "upk_stream_destroy", "upk_probe_placement", "upk_probe_clock",
 ]
 
 F_SILU, F_GEGLU, F_OUT_F32, F_OUT_NCHW_F32, F_UPSAMPLE2X, F_PAD_ASYM = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
@@ -186,6 +186,7 @@ def load_library(path=None):
             "upk_stream_create_cumask": (C.c_int, [vp, C.POINTER(C.c_uint32), i32, C.POINTER(vp)]),
             "upk_stream_destroy": (C.c_int, [vp, vp]),
             "upk_probe_placement": (C.c_int, [vp, vp, i32, i32, vp]),
+            "upk_probe_clock": (C.c_int, [vp, vp, i64, vp]),
         }
         require(sorted(protos) == sorted(SYMBOLS), "ctypes prototypes and SYMBOLS differ", RuntimeError)
         for name, (res, args) in protos.items():

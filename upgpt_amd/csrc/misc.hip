@@ -546,6 +546,27 @@ __global__ void probe_placement_kernel(uint32_t* out, int spin) {
   }
 }
 
+// shader clock against the constant 100 MHz wall clock over ~spin_wall_ticks wall ticks: the frequency the CU really runs at
+// while whatever else is in flight keeps the chip at its power limit
+__global__ void probe_clock_kernel(unsigned long long* out, long long spin_wall_ticks) {
+  if (threadIdx.x == 0) {
+    const unsigned long long w0 = wall_clock64(), c0 = clock64();
+    unsigned long long w1 = w0;
+    while ((long long)(w1 - w0) < spin_wall_ticks) {
+      __builtin_amdgcn_s_sleep(16);
+      w1 = wall_clock64();
+    }
+    out[0] = clock64() - c0;
+    out[1] = w1 - w0;
+  }
+}
+
+extern "C" int upk_probe_clock(upk_ctx* ctx, unsigned long long* out_dev, long long spin_wall_ticks, upk_stream stream) {
+  if (!ctx || !out_dev || spin_wall_ticks <= 0) return upk_fail(ctx, UPK_EINVAL, "upk_probe_clock: bad argument");
+  hipLaunchKernelGGL(probe_clock_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_dev, spin_wall_ticks);
+  return upk_check_launch(ctx, "probe_clock");
+}
+
 extern "C" int upk_stream_create_cumask(upk_ctx* ctx, const uint32_t* mask, int nwords, upk_stream* out) {
   if (!ctx || !mask || nwords <= 0 || !out) return upk_fail(ctx, UPK_EINVAL, "upk_stream_create_cumask: bad argument");
   hipStream_t s = nullptr;

@@ -34,61 +34,55 @@ def step_lane(k, n_lanes):
     return k % n_lanes
 
 
-# ---- CU-partitioned lane streams: a lane's kernels only on its own XCDs
+# ---- CU-partitioned lane streams: a lane's kernels only on its own CUs
+# What the CU mask of an HSA queue does on this driver, measured (scripts/r6_lanes_lab.py maskdiag,
+# profiles/r06_cu_mask_semantics.txt): mask bit b addresses CU slot b // 8 of XCD b % 8, and an XCD whose bits are ALL zero
+# is unrestricted.  A stream can therefore not be confined to a subset of the XCDs (the rationale of the experiment:
+# a lane's activations inside two L2s); what can be built is a partition by CU SLOT: lane l gets slots [l * 32 / n,
+# (l + 1) * 32 / n) of every XCD — disjoint CUs, all eight L2s shared as before.
 N_XCD, N_CU = 8, 256
 
 
-def cu_mask_words(xcds, scheme):
-    """CU mask (N_CU bits as 32-bit words) that allows exactly the CUs of the XCDs in `xcds`.  How mask bits map to XCDs is a
-    driver convention, so both candidates exist and the caller MEASURES which one the box uses (probe_placement):
-    "interleaved" bit b -> XCD b % 8 (what the KFD does for multi-XCC parts), "blocked" bit b -> XCD b // 32."""
-    require(scheme in ("interleaved", "blocked"), "unknown CU-mask scheme", ValueError)
+def cu_slot_mask_words(slots):
+    """CU mask (N_CU bits as 32-bit words) allowing CU slots `slots` (0..31) of every XCD: bit b <-> slot b // 8 of XCD b % 8."""
     words = [0] * (N_CU // 32)
     for b in range(N_CU):
-        x = b % N_XCD if scheme == "interleaved" else b // (N_CU // N_XCD)
-        if x in xcds:
+        if b // N_XCD in slots:
             words[b // 32] |= 1 << (b % 32)
     return words
 
 
 def probe_placement(ctx, stream, nblocks=2048, spin=40000):
-    """-> (set of XCC ids, number of distinct CUs) the workgroups of a launch on `stream` ran on (upk_probe_placement)."""
+    """-> {xcd: number of distinct CUs} the workgroups of a launch on `stream` ran on (upk_probe_placement)."""
     import ctypes as C
     out = torch.zeros(nblocks * 2, dtype=torch.int32, device=ctx.device)
     ptr = stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream)
     ctx._chk(ctx.lib.upk_probe_placement(ctx.h, out.data_ptr(), nblocks, spin, C.c_void_p(ptr)))
     torch.cuda.synchronize(ctx.device)
     v = out.cpu().view(nblocks, 2)
-    xcc = (v[:, 0] & 0xF).tolist()
-    cu = ((v[:, 1] >> 8) & 0xFF).tolist()  # HW_ID[15:8] = {se_id, sh_id, cu_id}
-    return set(xcc), len(set(zip(xcc, cu)))
+    seen = {}
+    for x, cu in zip((v[:, 0] & 0xF).tolist(), ((v[:, 1] >> 8) & 0xFF).tolist()):  # HW_ID[15:8] = {se_id, sh_id, cu_id}
+        seen.setdefault(x, set()).add(cu)
+    return {x: len(c) for x, c in sorted(seen.items())}
 
 
-def cu_partition_streams(ctx, parts):
-    """One HIP stream per entry of `parts` (each a collection of XCD indices), restricted to the CUs of those XCDs
-    (upk_stream_create_cumask), wrapped as torch.cuda.ExternalStream.  The mask-bit -> XCD convention is measured: the
-    first partition is created under each scheme until the probe kernel reports exactly its XCDs.  Returns (streams,
-    scheme, [(xcds seen, distinct CUs) per stream]); raises when no scheme confines the probe."""
+def cu_partition_streams(ctx, n):
+    """n HIP streams on disjoint CU sets: stream l may use CU slots [l * 32 // n, (l + 1) * 32 // n) of every XCD
+    (upk_stream_create_cumask), wrapped as torch.cuda.ExternalStream.  Returns (streams, [placement of the probe kernel per
+    stream]); raises when the probe finds a stream on more CUs than its mask allows (another mask convention)."""
     import ctypes as C
-
-    def make(xcds, scheme):
-        words = cu_mask_words(set(xcds), scheme)
+    require(1 <= n <= 32 and 32 % n == 0, "CU partitions: n must divide the 32 CU slots of an XCD", ValueError)
+    streams, seen = [], []
+    for l in range(n):
+        words = cu_slot_mask_words(set(range(l * 32 // n, (l + 1) * 32 // n)))
         arr = (C.c_uint32 * len(words))(*words)
         h = C.c_void_p()
         ctx._chk(ctx.lib.upk_stream_create_cumask(ctx.h, arr, len(words), C.byref(h)))
-        return torch.cuda.ExternalStream(h.value, device=ctx.device)
-
-    scheme = None
-    for cand in ("interleaved", "blocked"):
-        s = make(parts[0], cand)
-        seen, _ = probe_placement(ctx, s)
-        ctx.lib.upk_stream_destroy(ctx.h, C.c_void_p(s.cuda_stream))
-        if seen == set(parts[0]):
-            scheme = cand
-            break
-    require(scheme is not None, "no CU-mask scheme confines a stream to XCDs %r on this device" % (list(parts[0]),), RuntimeError)
-    streams = [make(p, scheme) for p in parts]
-    return streams, scheme, [probe_placement(ctx, s) for s in streams]
+        s = torch.cuda.ExternalStream(h.value, device=ctx.device)
+        streams.append(s)
+        seen.append(probe_placement(ctx, s))
+        require(sum(seen[-1].values()) <= N_CU // n, lambda: "CU mask not honoured as expected: %r" % (seen[-1],), RuntimeError)
+    return streams, seen
 
 
 class LanePool:
