@@ -174,6 +174,53 @@ elif MODE == "maskdiag":
             print("%d words, %-28s: %d CUs on XCDs %s" % (nwords, name, sum(hh.values()), hh), flush=True)
             ctx0.lib.upk_stream_destroy(ctx0.h, C.c_void_p(s.cuda_stream))
 
+elif MODE == "morelanes":
+    # more than four batches in flight: the runtime multiplexes ordinary streams onto 4 hardware queues, a stream created with a
+    # CU mask gets a queue of its own — with ALL CUs allowed it is an ordinary lane stream on a fifth, sixth, ... queue
+    import ctypes
+    pool = LanePool(4)
+    ctx0 = L.get_context(0, lane=0)
+    full = (ctypes.c_uint32 * 8)(*([0xFFFFFFFF] * 8))
+    xs = []
+    for _ in range(8):
+        h = ctypes.c_void_p()
+        ctx0._chk(ctx0.lib.upk_stream_create_cumask(ctx0.h, full, 8, ctypes.byref(h)))
+        xs.append(torch.cuda.ExternalStream(h.value))
+    ov = [[int(pool._overlap(a, b, 200000)[0]) if a is not b else 0 for b in xs] for a in xs]
+    print("pairwise overlap of 8 full-mask streams (1 = run concurrently):")
+    for r in ov:
+        print("   ", r)
+    ov2 = [int(pool._overlap(pool.streams[0], b, 200000)[0]) for b in xs]
+    print("pool stream 0 against them:", ov2, flush=True)
+    base = [lane_plan(i, s, 4) for i, s in enumerate(pool.streams)]
+    print("4 lanes, runtime streams (bench mode)      : %.3f ms per forward" % replay(base, list(pool.streams)), flush=True)
+    for n in (4, 5, 6, 8):
+        plans = [lane_plan(i, s, 4) for i, s in enumerate(xs[:n])]
+        print("%d lanes, full-mask streams (own queues)    : %.3f ms per forward" % (n, replay(plans, xs[:n])), flush=True)
+
+elif MODE == "knobs":
+    # row-chain kernels at the 16x16 level with the chip shared: 64-workgroup launches are what four lanes want
+    from upgpt_amd import knobs
+    pool = LanePool(4)
+    streams = list(pool.streams)
+    for name, kv in (("default", {}), ("XBLOCK=1", {"XBLOCK": "1"}), ("MLP_FUSE=1", {"MLP_FUSE": "1"}), ("XBLOCK=1 MLP_FUSE=1", {"XBLOCK": "1", "MLP_FUSE": "1"}),
+                     ("XBLOCK=1 XB_ROWS=16", {"XBLOCK": "1", "XB_ROWS": 16}), ("default again", {})):
+        old = {k: getattr(knobs, k) for k in kv}
+        for k, v in kv.items():
+            setattr(knobs, k, v)
+        for pl in list(unet._plans.values()):
+            pl.close()
+        unet._plans.clear()
+        try:
+            plans = [lane_plan(i, s, 4) for i, s in enumerate(streams)]
+            labs = [l for l in plans[0].body.labels if l.startswith(("xblock", "mlp", "hblock"))]
+            ms = replay(plans, streams, reps=12)
+            print("%-24s %.3f ms per forward (%d kernels; row-chain ops: %s)" % (name, ms, len(plans[0].body.labels), sorted(set(labs))), flush=True)
+        except Exception as e:
+            print("%-24s failed: %s" % (name, str(e)[:200]), flush=True)
+        for k, v in old.items():
+            setattr(knobs, k, v)
+
 elif MODE == "clock":
     # shader clock under load: a spinning probe wave on a fifth stream while 0 / 1 / 4 lanes replay forwards
     pool = LanePool(4)
