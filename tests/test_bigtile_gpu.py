@@ -34,6 +34,8 @@ def test_family_is_listed_behind_the_others(ctx):
     (2, 512, 512, (16, 24), 3),   # K = 4608: 144 stages
     (3, 64, 320, (20, 20), 1),    # 1x1, N not a tile multiple
     (1, 96, 132, (9, 7), 3),      # smaller than one tile in both dimensions
+    (2, 224, 224, (32, 20), 3),   # the 7 * 32-channel family: N = one 224-wide tile (14 row groups dealt unevenly to 4 / 8 waves)
+    (1, 448, 448, (16, 16), 1),   # ... N = two 224-wide / four 112-wide tiles, 1x1
 ])
 def test_every_configuration_matches_conv2d(ctx, B, cin, cout, hw, ks):
     H, W = hw

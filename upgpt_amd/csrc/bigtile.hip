@@ -65,8 +65,13 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2, 
   static_assert(NW == 4 || NW == 8, "two waves per SIMD");
   constexpr int BM = MI * 16 * WM, BN = NI * 16 * WN;
   constexpr int AG = BM / 16, BG = BN / 16;
-  static_assert(AG % NW == 0 && BG % NW == 0, "row groups are dealt to the waves");
-  constexpr int AGW = AG / NW, BGW = BG / NW, P = AGW + BGW;  // DMAs per wave per stage
+  // the 16-row groups of the A and the B tile are dealt to the waves round robin.  The 7 * 32-channel family (N tiles of
+  // 112 / 224 columns: 7 / 14 groups) does not divide by the wave count: every wave still issues P DMAs per stage — the
+  // waits are COUNTED — and the surplus ones of the waves with fewer groups fetch the zero page into a 1 KiB dump row group
+  // behind the ring (as the wave-specialised loaders of igemm.hip do)
+  constexpr int AGW = (AG + NW - 1) / NW, BGW = (BG + NW - 1) / NW, P = AGW + BGW;  // DMAs per wave per stage
+  constexpr bool UNEVEN = (AG % NW != 0) || (BG % NW != 0);
+  constexpr int DUMP = UNEVEN ? 512 : 0;
   constexpr int ROWS = BM + BN;
   constexpr int STAGE = ROWS * 32;    // halfs per ring slot (one K chunk)
   constexpr int L = LA ? 1 : 0;         // look-ahead: the barrier of stage t also guarantees stage t + 1
@@ -74,8 +79,9 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2, 
   static_assert(KEEP >= 1 && KEEP <= 2 && (KEEP + 1) * P <= 63, "vmcnt range");
   static_assert(MI + NI - 1 <= 15, "lgkmcnt range");
   static_assert(BM * 64 + (NI - 1) * 1024 < 65536, "ds_read offsets");
-  static_assert(NBUF * STAGE * 2 <= 160 * 1024, "LDS");
-  __shared__ __attribute__((aligned(16))) f16 smem[NBUF * STAGE];
+  static_assert((NBUF * STAGE + DUMP) * 2 <= 160 * 1024, "LDS");
+  static_assert(WM * WN * NI * 32 * 4 <= NBUF * STAGE * 2, "tile_plain_cp scratch");
+  __shared__ __attribute__((aligned(16))) f16 smem[NBUF * STAGE + DUMP];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2, 
 #pragma unroll
   for (int i = 0; i < AGW; ++i) {
     const int m = m0 + (wave + NW * i) * 16 + r16;
-    const bool ok = m < a.M;
+    const bool ok = m < a.M && (!UNEVEN || wave + NW * i < AG);
     const int mm = ok ? m : 0;
     if (a.linear) {
       a_b[i] = 0;
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2, 
 #pragma unroll
   for (int i = 0; i < BGW; ++i) {
     const int row = (wave + NW * i) * 16 + r16;
-    const bool ok = n0 + row < a.npad;
+    const bool ok = n0 + row < a.npad && (!UNEVEN || wave + NW * i < BG);
     bp[i] = ok ? a.w + (long)ph * a.ph_wstride + ((long)kc0 * a.npad + n0 + row) * 32 + chd * 8 : nullptr;
   }
   const long wstep = (long)a.npad * 32;
@@ -158,12 +164,16 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(2, 
     for (int i = 0; i < AGW; ++i) {
       const f16* p = second ? ap2[i] : ap1[i];
       const f16* src = p ? p + cur_c0 : zsrc;
-      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(base + (wave + NW * i) * 16 * 32), 16, 0, 0);
+      f16* dst = base + (wave + NW * i) * 16 * 32;
+      if constexpr (UNEVEN) dst = (wave + NW * i < AG) ? dst : smem + NBUF * STAGE;  // (wave-uniform)
+      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)dst, 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < BGW; ++i) {
       const f16* src = bp[i] ? bp[i] : zsrc;
-      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(base + (BM + (wave + NW * i) * 16) * 32), 16, 0, 0);
+      f16* dst = base + (BM + (wave + NW * i) * 16) * 32;
+      if constexpr (UNEVEN) dst = (wave + NW * i < BG) ? dst : smem + NBUF * STAGE;
+      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)dst, 16, 0, 0);
       if (bp[i]) bp[i] += wstep;
     }
     ++cur_kc;
@@ -390,6 +400,12 @@ const BtCfg kBt[] = {
     BTC(8, 4, 2, 4, 4, true),  // 256x256 (wave 128x64)
     BTC(4, 8, 8, 1, 4, true),  // 512x128, 160 KB ring (N = 128 layers)
     BTC(4, 4, 4, 2, 4, true),  // 256x128,  96 KB ring (wave 64x64)
+    // the 7 * 32-channel family of the UNet (N = 224, 448, 896, 1792): tiles of 224 / 112 columns without padding waste
+    // (round 6).  Two resident workgroups per CU: 67.6 / 70.7 KB rings, 4 waves, <= 256 registers
+    BTCF(4, 7, 2, 2, 3, false),  // 128x224 (wave 64x112)
+    BTCF(4, 7, 4, 1, 3, false),  // 256x112 (wave 64x112: A rows private, B shared)
+    // 8 waves, one workgroup per CU, look-ahead: half the weight bytes per output of the 128-row tiles
+    BTC(4, 7, 4, 2, 4, true),    // 256x224, 120 KB ring (wave 64x112)
 };
 constexpr int kNumBt = sizeof(kBt) / sizeof(kBt[0]);
 
