@@ -277,8 +277,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 // LNF: the MFMA waves also take the folded LayerNorm's row statistics (IgemmArgs::ln_u) — likewise its own
 // instantiation (M x N split configurations only): a wave-uniform test per K chunk and 2*MI live registers less in
 // the kernels every other launch uses.
-template <int MI, int NI, int WM, int WN, int KS, int NBUF, bool APP = false, bool LNF = false>
-__global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
+// LW: loader waves (4, or 8 in the "...l8" configurations of round 6: the loaders' DMA ISSUE — each global_load_lds holds its
+// wave 60-185 cycles — is what bounds the K loop's fill at ~29 B/clk per CU; twice the issuers on the same ring.  Loader
+// waves 4 .. LW-1 take no part in the shared epilogue and leave after the K loop.)
+template <int MI, int NI, int WM, int WN, int KS, int NBUF, bool APP = false, bool LNF = false, int LW = 4>
+__global__ __launch_bounds__(256 + LW * 64) void igemm_ws_kernel(const IgemmArgs a) {
   // WM*WN == 4: the 4 MFMA waves tile the block in M x N (each a MI x NI register tile).
   // WM*WN == 1: K-SPLIT mode — every MFMA wave owns the WHOLE MI x NI block tile and takes every
   // 4th K-chunk; the four accumulators are summed through LDS once at the end (fixed order).
@@ -291,7 +294,8 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
   constexpr int BM = MI * 16 * WM;
   constexpr int BN = NI * 16 * WN;
   constexpr int AG = BM / 16, BG = BN / 16;          // 16-row groups (1 KiB = one wave DMA)
-  constexpr int AGW = (AG + 3) / 4, BGW = (BG + 3) / 4;  // groups per loader wave
+  static_assert(LW == 4 || (LW == 8 && !KSPLIT), "loader waves");
+  constexpr int AGW = (AG + LW - 1) / LW, BGW = (BG + LW - 1) / LW;  // groups per loader wave
   constexpr int P = KS * (AGW + BGW);                 // DMAs per loader wave per stage
   constexpr int D = NBUF - 1;                         // prefetch distance in stages
   static_assert(D * P <= 63, "vmcnt range");
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
     const int HoWo = a.Ho * a.Wo;
 #pragma unroll
     for (int i = 0; i < AGW; ++i) {
-      const int rg = lw + 4 * i;
+      const int rg = lw + LW * i;
       const int m = m0 + rg * 16 + r16;
       a_ok[i] = (rg < AG) && (m < a.M);
       const int mm = a_ok[i] ? m : 0;
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
     bool b_ok[BGW];
 #pragma unroll
     for (int i = 0; i < BGW; ++i) {
-      const int rg = lw + 4 * i;
+      const int rg = lw + LW * i;
       const int row = rg * 16 + r16;
       b_ok[i] = (rg < BG) && (n0 + row < a.npad);
       bp[i] = a.w + (long)ph * a.ph_wstride + ((long)kc0 * a.npad + n0 + row) * 32 + chd * 8;
@@ -432,14 +436,14 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
         const bool second = cur_c0 >= sc1;
 #pragma unroll
         for (int i = 0; i < AGW; ++i) {
-          const int rg = lw + 4 * i;  // wave-uniform
+          const int rg = lw + LW * i;  // wave-uniform
           const f16* src = (live && tap_ok[i]) ? ((second ? ap2[i] : ap1[i]) + cur_c0) : zsrc;
           f16* dst = (rg < AG) ? base + (s * ROWS + rg * 16) * 32 : smem + NBUF * STAGE;
           __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)dst, 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < BGW; ++i) {
-          const int rg = lw + 4 * i;
+          const int rg = lw + LW * i;
           const f16* src = (live && b_ok[i]) ? bp[i] : zsrc;
           f16* dst = (rg < BG) ? base + (s * ROWS + BM + rg * 16) * 32 : smem + NBUF * STAGE;
           // (nt on the weight stream of the split-K launches — each line read once by one or two workgroups — measured
@@ -497,6 +501,9 @@ __global__ __launch_bounds__(512) void igemm_ws_kernel(const IgemmArgs a) {
 #ifdef UPK_KSPLIT_EPI4  // (A/B builds: the four MFMA waves alone)
     return;
 #else
+    if constexpr (LW > 4) {
+      if (lw >= 4) return;  // (a finished wave no longer counts at the workgroup's barriers)
+    }
     if constexpr (!KSPLIT) {
       if constexpr (SHARE) {
         if ABL_ON(ABL_NOEPI) return;
@@ -1121,6 +1128,7 @@ struct CfgInfo {
   int nbuf;  // 0: classic register-staged kernel; > 0: wave-specialised DMA kernel (512 threads)
   void (*fn_app)(const IgemmArgs);  // variant whose loader walks an appended 1x1 K segment, or nullptr
   void (*fn_ln)(const IgemmArgs);   // variant whose MFMA waves take the folded LayerNorm's row statistics, or nullptr
+  int lw = 4;                       // loader waves of the wave-specialised kernel (threads = 256 + 64 lw)
 };
 
 template <int MI, int NI, int WM, int WN, int KS, int NB>
@@ -1133,7 +1141,11 @@ constexpr void (*ws_ln_fn())(const IgemmArgs) {
   {MI, NI, WM, WN, KS, #MI "x" #NI "x" #WM "x" #WN "k" #KS, igemm_kernel<MI, NI, WM, WN, KS>, 0, nullptr, nullptr}
 #define CFGW(MI, NI, WM, WN, KS, NB) \
   {MI, NI, WM, WN, KS, #MI "x" #NI "x" #WM "x" #WN "k" #KS "w" #NB, igemm_ws_kernel<MI, NI, WM, WN, KS, NB>, NB, \
-   igemm_ws_kernel<MI, NI, WM, WN, KS, NB, true>, ws_ln_fn<MI, NI, WM, WN, KS, NB>()}
+   igemm_ws_kernel<MI, NI, WM, WN, KS, NB, true>, ws_ln_fn<MI, NI, WM, WN, KS, NB>(), 4}
+// eight loader waves (768 threads); plain and appended-segment loaders, no fragment-side LayerNorm fold
+#define CFGW8(MI, NI, WM, WN, KS, NB) \
+  {MI, NI, WM, WN, KS, #MI "x" #NI "x" #WM "x" #WN "k" #KS "w" #NB "l8", igemm_ws_kernel<MI, NI, WM, WN, KS, NB, false, false, 8>, NB, \
+   igemm_ws_kernel<MI, NI, WM, WN, KS, NB, true, false, 8>, nullptr, 8}
 // (MI, NI, WM, WN, KS): block tile = (MI*16*WM) x (NI*16*WN), WM*WN waves, KS K-chunks/stage.
 const CfgInfo kCfgs[] = {
     CFG(4, 4, 2, 2, 1), CFG(4, 4, 2, 2, 2),  // 128x128
@@ -1164,6 +1176,9 @@ const CfgInfo kCfgs[] = {
     // 64-512 output rows; with 2 stages in flight each workgroup pays one HBM round trip per ~32 KB
     CFGW(2, 4, 2, 2, 2, 6), CFGW(4, 4, 2, 2, 1, 6), CFGW(2, 2, 2, 2, 2, 8), CFGW(2, 7, 4, 1, 1, 6),
     CFGW(1, 4, 4, 1, 2, 8), CFGW(4, 2, 2, 2, 2, 6),
+    // round 6, generation 2 of VERDICT r05 item 1: the 128x224 / 128x128 tiles of the shared-chip table with
+    // (a) one-chunk stages on a 6-slot ring (112 KB in flight instead of 90, a barrier per chunk), (b) eight loader waves
+    CFGW(4, 7, 2, 2, 1, 6), CFGW8(4, 7, 2, 2, 2, 3), CFGW8(4, 7, 2, 2, 1, 6), CFGW8(4, 4, 2, 2, 2, 3), CFGW8(2, 7, 2, 2, 2, 3),
     // (256x128 / 128x256 tiles — 85 FLOP per filled byte against 64 — were tried for the VAE decoder's long convs:
     // 128 accumulator registers + the plain / statistics epilogues spill 50-200 VGPRs at 2 waves per SIMD; not kept)
 };
@@ -1552,7 +1567,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   int rc;
   if (is_bt) rc = bt_launch(ctx, a, best - bt0, grid, stream);
   else {
-  hipLaunchKernelGGL((a.ln_u && !a.lnr_in) ? c.fn_ln : (a.x3 ? c.fn_app : c.fn), grid, dim3(c.nbuf ? 512 : c.wm * c.wn * 64), 0, stream, a);
+  hipLaunchKernelGGL((a.ln_u && !a.lnr_in) ? c.fn_ln : (a.x3 ? c.fn_app : c.fn), grid, dim3(c.nbuf ? 256 + 64 * c.lw : c.wm * c.wn * 64), 0, stream, a);
   rc = upk_check_launch(ctx, "igemm");
   }
   if (rc) return rc;

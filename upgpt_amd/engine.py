@@ -266,12 +266,12 @@ class VAEDecodePlan(Emitter):
         for Lr in a.decoder:
             n = Lr.name
             if Lr.kind == "conv":
-                x = self.conv(P, x, W_[n], gn_stats=K.VAE_GN_BYPRODUCT)
+                x = self.conv(P, x, W_[n], gn_stats=K.vae_gn_byproduct(x.M))
             elif Lr.kind == "resnet":
-                h1 = self.conv(P, x, W_[n + ".conv1"], gn=(*V_[n + ".norm1"], 1e-6, True, self.gn_ws), gn_stats=K.VAE_GN_BYPRODUCT)
+                h1 = self.conv(P, x, W_[n + ".conv1"], gn=(*V_[n + ".norm1"], 1e-6, True, self.gn_ws), gn_stats=K.vae_gn_byproduct(x.M))
                 sk = self.conv(P, x, W_[n + ".nin_shortcut"]) if Lr.cin != Lr.cout else x
                 x = self.conv(P, h1, W_[n + ".conv2"], residual=sk, gn=(*V_[n + ".norm2"], 1e-6, True, self.gn_ws),
-                              gn_stats=K.VAE_GN_BYPRODUCT)
+                              gn_stats=K.vae_gn_byproduct(x.M))
             elif Lr.kind == "attn":
                 c, HW = Lr.ch, x.H * x.W
                 xn = self.groupnorm(P, x, *V_[n + ".norm"], 1e-6, False, self.gn_ws)
@@ -283,7 +283,7 @@ class VAEDecodePlan(Emitter):
                 ao = Act(self.alloc(x.M, c), x.B, x.H, x.W, c)
                 self.attention(P, qk.t, 2 * c, HW * 2 * c, qk.t[:, c:], 2 * c, HW * 2 * c, vt, vt_ld, ao.t, c, HW * c,
                                x.B, 1, HW, HW, c, int(c) ** -0.5)
-                x = self.conv(P, ao, W_[n + ".proj_out"], residual=x, gn_stats=K.VAE_GN_BYPRODUCT)
+                x = self.conv(P, ao, W_[n + ".proj_out"], residual=x, gn_stats=K.vae_gn_byproduct(x.M))
             elif Lr.kind == "upconv":
                 x = self.conv(P, x, W_[n], flags=L.F_UPSAMPLE2X)
             elif Lr.kind == "norm_out":
@@ -324,12 +324,12 @@ class VAEEncodePlan(Emitter):
         for Lr in a.encoder:
             n = Lr.name
             if Lr.kind == "conv":
-                x = self.conv(P, x, W_[n], gn_stats=K.VAE_GN_BYPRODUCT)
+                x = self.conv(P, x, W_[n], gn_stats=K.vae_gn_byproduct(x.M))
             elif Lr.kind == "resnet":
-                h1 = self.conv(P, x, W_[n + ".conv1"], gn=(*V_[n + ".norm1"], 1e-6, True, self.gn_ws), gn_stats=K.VAE_GN_BYPRODUCT)
+                h1 = self.conv(P, x, W_[n + ".conv1"], gn=(*V_[n + ".norm1"], 1e-6, True, self.gn_ws), gn_stats=K.vae_gn_byproduct(x.M))
                 sk = self.conv(P, x, W_[n + ".nin_shortcut"]) if Lr.cin != Lr.cout else x
                 x = self.conv(P, h1, W_[n + ".conv2"], residual=sk, gn=(*V_[n + ".norm2"], 1e-6, True, self.gn_ws),
-                              gn_stats=K.VAE_GN_BYPRODUCT)
+                              gn_stats=K.vae_gn_byproduct(x.M))
             elif Lr.kind == "attn":
                 c, HW = Lr.ch, x.H * x.W
                 xn = self.groupnorm(P, x, *V_[n + ".norm"], 1e-6, False, self.gn_ws)

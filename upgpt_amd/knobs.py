@@ -4,7 +4,14 @@ import os
 # GroupNorm statistics of the VAE decoder's tensors as conv by-products (gn_stats_cap + upk_groupnorm_finalize_f32):
 # measured neutral (8.29 vs 8.29 ms per decode) — the statistics pass runs at 5.6 TB/s since round 2, the channel
 # partials cost the 200-us convs 2-3 % and a 32-block fold per apply workgroup more than the pass it replaces — off
-VAE_GN_BYPRODUCT = os.environ.get("UPGPT_VAE_GN_BYPRODUCT", "0") == "1"
+VAE_GN_BYPRODUCT = os.environ.get("UPGPT_VAE_GN_BYPRODUCT", "0")  # "0" | "1" | "auto" (only tensors of >= VAE_GN_MINM rows)
+VAE_GN_MINM = int(os.environ.get("UPGPT_VAE_GN_MINM", "131072"))
+
+
+def vae_gn_byproduct(M):
+    """Whether the producer conv of an M-row VAE tensor leaves the GroupNorm statistics (round 6: "auto" arms only the two
+    highest-resolution levels, where the statistics pass it replaces costs 13-51 us against 2-3 % of a 200-us conv)."""
+    return VAE_GN_BYPRODUCT == "1" or (VAE_GN_BYPRODUCT == "auto" and M >= VAE_GN_MINM)
 UPS_PHASES = os.environ.get("UPGPT_UPS_PHASES", "1") == "1"
 LN_ROWS = os.environ.get("UPGPT_LN_ROWS", "1") == "1"
 QPROJ_FUSE = os.environ.get("UPGPT_QPROJ_FUSE", "1") == "1"
