@@ -38,15 +38,17 @@ def summarize(name, emitter):
 
 for kind in kinds:
     with contextlib.redirect_stdout(io.StringIO()):
-        model = upgpt_amd.build_model("bbox" if kind in ("bbox_cfg", "bbox_small") else kind)
+        model = upgpt_amd.build_model("bbox" if kind in ("bbox_cfg", "bbox_small") else ("upscale" if kind == "upscale_true" else kind))
     synth.fill_module_(model)
     model = model.cuda()
     unet = model.model.diffusion_model
     C = model.channels
-    ntok = 86 if kind == "upscale" else 87
+    ntok = 86 if kind in ("upscale", "upscale_true") else 87
     shapes = [(8, 32, 32, 50), (8, 32, 24, 50)] if kind == "bbox" else [(4, 64, 64, 50)]
     if kind == "bbox_cfg":  # classifier-free guidance runs the UNet on 2*B rows
         shapes, kind = [(16, 32, 32, 50), (16, 32, 24, 50)], "bbox"
+    if kind == "upscale_true":  # BASELINE configs[4] at the size the reference's config states: latent 3 x 128 x 96, bs 4
+        shapes, kind = [(4, 128, 96, 50)], "upscale"
     if kind == "bbox_small":  # the demo's batch sizes (app.py: 1 sample, interpolation rows of 2-4), 256x192
         shapes, kind = [(1, 32, 24, 50), (2, 32, 24, 50), (4, 32, 24, 50)], "bbox"
     for (B, H, W, S) in shapes:
@@ -69,6 +71,8 @@ for kind in kinds:
         os.environ.pop("UPGPT_SKIP_FOLD", None)
         os.environ.pop("UPGPT_FFOUT_FOLD", None)
         unet._plans.clear()
+        if os.environ.get("TUNE_NO_VAE", "0") == "1":
+            continue
         t0 = time.time()
         vp = model.first_stage_model._decode_plan(B, H, W, 0.18215)
         summarize("%s vae decode B=%d %dx%d (%.0fs)" % (kind, B, H, W, time.time() - t0), vp)

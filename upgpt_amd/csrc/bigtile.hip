@@ -400,12 +400,17 @@ const BtCfg kBt[] = {
     BTC(8, 4, 2, 4, 4, true),  // 256x256 (wave 128x64)
     BTC(4, 8, 8, 1, 4, true),  // 512x128, 160 KB ring (N = 128 layers)
     BTC(4, 4, 4, 2, 4, true),  // 256x128,  96 KB ring (wave 64x64)
+#ifdef UPK_R6_EXPERIMENTS
     // the 7 * 32-channel family of the UNet (N = 224, 448, 896, 1792): tiles of 224 / 112 columns without padding waste
-    // (round 6).  Two resident workgroups per CU: 67.6 / 70.7 KB rings, 4 waves, <= 256 registers
+    // (round 6, generation 1 of VERDICT r05 item 1).  Two resident workgroups per CU: 67.6 / 70.7 KB rings,
+    // 4 waves, <= 256 registers; and the 8-wave 256x224 tile with half the weight bytes per output.  Parity-green
+    // (tests/test_bigtile_gpu.py runs every listed configuration), and slower by chip time on every UNet shape
+    // (profiles/r06_gen1_bigtile_224_columns_chip_time.txt: 12.3-15.2 us against 9.5 on the level-0 3x3 conv): with
+    // 64-workgroup launches on four lanes there is ONE workgroup per CU, and this family needs its sibling.  Dev builds only.
     BTCF(4, 7, 2, 2, 3, false),  // 128x224 (wave 64x112)
     BTCF(4, 7, 4, 1, 3, false),  // 256x112 (wave 64x112: A rows private, B shared)
-    // 8 waves, one workgroup per CU, look-ahead: half the weight bytes per output of the 128-row tiles
     BTC(4, 7, 4, 2, 4, true),    // 256x224, 120 KB ring (wave 64x112)
+#endif
 };
 constexpr int kNumBt = sizeof(kBt) / sizeof(kBt[0]);
 

@@ -1176,9 +1176,14 @@ const CfgInfo kCfgs[] = {
     // 64-512 output rows; with 2 stages in flight each workgroup pays one HBM round trip per ~32 KB
     CFGW(2, 4, 2, 2, 2, 6), CFGW(4, 4, 2, 2, 1, 6), CFGW(2, 2, 2, 2, 2, 8), CFGW(2, 7, 4, 1, 1, 6),
     CFGW(1, 4, 4, 1, 2, 8), CFGW(4, 2, 2, 2, 2, 6),
-    // round 6, generation 2 of VERDICT r05 item 1 (DESIGN.md 14): the 128x224 / 128x128 tiles of the shared-chip table with
-    // (a) one-chunk stages on a 6-slot ring (112 KB in flight instead of 90, a barrier per chunk), (b) eight loader waves
+#ifdef UPK_R6_EXPERIMENTS
+    // round 6, generation 2 of VERDICT r05 item 1 (DESIGN.md 14b): the 128x224 / 128x128 tiles of the shared-chip table with
+    // (a) one-chunk stages on a 6-slot ring (112 KB in flight instead of 90, a barrier per chunk), (b) eight loader waves.
+    // Measured by chip time (profiles/r06_gen2_eight_loader_waves_deep_ring_chip_time.txt): 9.72 / 9.90 against 9.67 us on
+    // the level-0 3x3 conv — neither the ring depth nor the number of DMA issuers bounds the K loop.  Dev builds only
+    // (UPK_CXXFLAGS=-DUPK_R6_EXPERIMENTS): a configuration that does not win does not ship.
     CFGW(4, 7, 2, 2, 1, 6), CFGW8(4, 7, 2, 2, 2, 3), CFGW8(4, 7, 2, 2, 1, 6), CFGW8(4, 4, 2, 2, 2, 3), CFGW8(2, 7, 2, 2, 2, 3),
+#endif
     // (256x128 / 128x256 tiles — 85 FLOP per filled byte against 64 — were tried for the VAE decoder's long convs:
     // 128 accumulator registers + the plain / statistics epilogues spill 50-200 VGPRs at 2 waves per SIMD; not kept)
 };
