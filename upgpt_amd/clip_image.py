@@ -22,6 +22,7 @@ from torch import nn
 
 from . import _lib as L
 from .engine import Act, Emitter, PW, Packer, Program, _rup
+from .packing import SharedPacks
 from .params import ParamTree, weights_fingerprint
 
 CLIP_L14_VISION = dict(width=1024, layers=24, heads=16, patch_size=14, image_size=224, output_dim=768, eps=1e-5)
@@ -47,7 +48,7 @@ def visual_param_shapes(cfg):
 class _VisualPlan(Emitter):
     """Launch program of the image tower for N images."""
 
-    def __init__(self, ctx, cfg, get, N):
+    def __init__(self, ctx, cfg, get, N, shared=None):
         super().__init__(ctx)
         self.cfg, self.N = cfg, N
         d, heads, p, img = cfg["width"], cfg["heads"], cfg["patch_size"], cfg["image_size"]
@@ -74,6 +75,8 @@ class _VisualPlan(Emitter):
             return get(n)
 
         pk = Packer(ctx, lookup)
+        if shared is not None:  # (the packed tower is shared by every lane's plan: 0.6 GB once, not once per lane)
+            pk = shared.wrap(pk)
         self.x = self.alloc(N, 3, img, img, dtype=torch.float32)
         patches = Act(self.alloc(N * npatch, kp), N, npatch, 1, kp)
         fn_p = self.lib.upk_patchify_nchw_f32_f16
@@ -117,13 +120,20 @@ class _VisualPlan(Emitter):
              y.t.data_ptr(), y.ld)
         P.add(lambda s: chk(fn(h, *a, s)), x, gamma, beta, y, cls="layernorm")
 
-    def run(self, images):
+    def upload(self, images):
+        """The only host -> device step of the tower (bracketed by _lib.host_io when the crops come from the host)."""
         img = self.cfg["image_size"]
         if tuple(images.shape) != (self.N, 3, img, img):
             raise ValueError("images must be [%d, 3, %d, %d], got %s" % (self.N, img, img, tuple(images.shape)))
         self.x.copy_(images.to(self.dev, torch.float32))
+
+    def execute(self):
         self.prog.run()
         return self.out.clone()
+
+    def run(self, images):
+        self.upload(images)
+        return self.execute()
 
 
 class CLIPVisual(ParamTree):
@@ -145,7 +155,7 @@ class CLIPVisual(ParamTree):
         with PLAN_LOCK:  # (execution lanes: a plan — buffers and packed weights — per (crop count, tuning table, lane))
             fp = weights_fingerprint(self)
             if fp != self._fp:
-                self._plans, self._fp = {}, fp
+                self._plans, self._fp, self._packs = {}, fp, SharedPacks()
             N = int(images.shape[0])
             key = (N, concurrency() > 1, current_lane())
             plan = self._plans.get(key)
@@ -155,10 +165,18 @@ class CLIPVisual(ParamTree):
                     self._plans.pop(mine[0])
                 params = dict(self.named_parameters())
                 with torch.cuda.device(p.device), host_io():
-                    plan = self._plans[key] = _VisualPlan(get_context(p.device), self.config, lambda n: params[n].data, N)
+                    plan = self._plans[key] = _VisualPlan(get_context(p.device), self.config, lambda n: params[n].data, N,
+                                                          shared=self._packs)
+                    if self._packs.take_fresh():
+                        torch.cuda.current_stream(p.device).synchronize()  # (packed on this lane's stream, read from every lane's)
+        import contextlib
         from ._lib import host_io
-        with torch.cuda.device(p.device), host_io():
-            return plan.run(images)
+        with torch.cuda.device(p.device):
+            # only the upload of crops that live on the host is serialised against other lanes' graph captures; the tower
+            # itself (eager launches on this lane's stream) overlaps with whatever the other lanes run
+            with (host_io() if not images.is_cuda else contextlib.nullcontext()):
+                plan.upload(images)
+            return plan.execute()
 
 
 class _CLIPModelShell(nn.Module):

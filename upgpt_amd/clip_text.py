@@ -27,6 +27,7 @@ from torch import nn
 
 from . import _lib as L
 from .engine import Act, Emitter, Packer, Program, _rup
+from .packing import SharedPacks
 from .params import ParamTree, weights_fingerprint
 
 # openai/clip-vit-large-patch14 text tower (config.json of the hub model; CLIPTextConfig)
@@ -82,7 +83,7 @@ def openai_text_param_shapes(cfg):
 class _TextPlan(Emitter):
     """Launch program of the text tower for one batch size."""
 
-    def __init__(self, ctx, cfg, get, B, names=HF_NAMES):
+    def __init__(self, ctx, cfg, get, B, names=HF_NAMES, shared=None):
         super().__init__(ctx)
         self.cfg, self.B, self.pooled = cfg, B, names["proj"] is not None
         nm, raw = names, get
@@ -100,6 +101,8 @@ class _TextPlan(Emitter):
             raise NotImplementedError("CLIP text tower with head dim %d / width %d" % (dh, d))
         eps = float(cfg["layer_norm_eps"])
         pk = Packer(ctx, get)
+        if shared is not None:  # (one packed tower for every lane's plan)
+            pk = shared.wrap(pk)
         M = B * S
         self.ids = self.alloc(M, dtype=torch.int32)
         self.tok = get(nm["tok"]).half().contiguous()
@@ -150,17 +153,28 @@ class _TextPlan(Emitter):
         self.apply_tuning(tune_missing=os.environ.get("UPGPT_AUTOTUNE", "0") == "1")
 
     def run(self, ids):
+        self.check(ids)
+        self.upload(ids)
+        return self.execute()
+
+    def check(self, ids):
         if tuple(ids.shape) != (self.B, self.cfg["max_position_embeddings"]):
             raise ValueError("token ids must be [%d, %d], got %s" % (self.B, self.cfg["max_position_embeddings"],
                                                                      tuple(ids.shape)))
         if int(ids.min()) < 0 or int(ids.max()) >= self.cfg["vocab_size"]:
             raise ValueError("token id outside [0, %d)" % self.cfg["vocab_size"])
+
+    def upload(self, ids):
+        """The host -> device part (token ids, end-of-text rows): what _lib.host_io brackets; shapes checked by run()."""
         self.ids.copy_(ids.reshape(-1).to(self.dev, torch.int32))
         if self.pooled:
             # end-of-text = the highest token id of each sequence (clip/model.py encode_text: text.argmax(dim=-1))
             S = self.cfg["max_position_embeddings"]
             eot = ids.argmax(dim=-1).to(torch.int64).cpu() + torch.arange(self.B, dtype=torch.int64) * S
             self.eot.copy_(eot.to(torch.int32))
+
+    def execute(self):
+        if self.pooled:
             self.prog.run()
             return self.out_f32.clone()
         self.prog.run()
@@ -187,7 +201,7 @@ class _TextTower(ParamTree):
         with PLAN_LOCK:  # (execution lanes: a plan — buffers and packed weights — per (batch, tuning table, lane))
             fp = weights_fingerprint(self)
             if fp != self._fp:
-                self._plans, self._fp = {}, fp
+                self._plans, self._fp, self._packs = {}, fp, SharedPacks()
             B = int(input_ids.shape[0])
             key = (B, concurrency() > 1, current_lane())
             plan = self._plans.get(key)
@@ -198,10 +212,15 @@ class _TextTower(ParamTree):
                 params = dict(self.named_parameters())
                 with torch.cuda.device(p.device), host_io():
                     plan = self._plans[key] = _TextPlan(get_context(p.device), self.config, lambda n: params[n].data, B,
-                                                        names=self.NAMES)
+                                                        names=self.NAMES, shared=self._packs)
+                    if self._packs.take_fresh():
+                        torch.cuda.current_stream(p.device).synchronize()
         from ._lib import host_io
-        with torch.cuda.device(p.device), host_io():  # (token ids come from the host: _lib.host_io)
-            return plan.run(input_ids)
+        with torch.cuda.device(p.device):
+            plan.check(input_ids)
+            with host_io():  # (token ids / end-of-text rows come from the host: only the upload is serialised, _lib.host_io)
+                plan.upload(input_ids)
+            return plan.execute()  # (eager launches on this lane's stream: overlaps with the other lanes)
 
 
 class CLIPTextTransformer(_TextTower):

@@ -24,6 +24,49 @@ class PW:
     __slots__ = ("w", "n_pad", "bias", "n_out", "k_packed", "ksize", "n_real", "k_real", "ln_colsum", "k_append", "w_phase")
 
 
+class SharedPacks:
+    """Packed operands of ONE weight set, built once and shared by the plans of every execution lane (the packs are
+    read-only device tensors: only activation buffers, descriptors and graphs are per lane).  wrap(packer) returns a packer
+    whose pack() / vec() results are memoised here; `fresh` counts the packs built since the last take_fresh() so that the
+    caller can drain the packing stream before another lane's stream reads them."""
+
+    def __init__(self):
+        self.d, self.fresh = {}, 0
+
+    def wrap(self, pk):
+        return _MemoPacker(pk, self)
+
+    def take_fresh(self):
+        n, self.fresh = self.fresh, 0
+        return n
+
+
+class _MemoPacker:
+    def __init__(self, pk, shared):
+        self._pk, self._sh = pk, shared
+
+    @staticmethod
+    def _key(kind, names, kw):
+        return (kind, tuple(names) if isinstance(names, (list, tuple)) else names, tuple(sorted(kw.items())))
+
+    def pack(self, names, **kw):
+        k = self._key("pack", names, kw)
+        if k not in self._sh.d:
+            self._sh.d[k] = self._pk.pack(names, **kw)
+            self._sh.fresh += 1
+        return self._sh.d[k]
+
+    def vec(self, name):
+        k = self._key("vec", name, {})
+        if k not in self._sh.d:
+            self._sh.d[k] = self._pk.vec(name)
+            self._sh.fresh += 1
+        return self._sh.d[k]
+
+    def __getattr__(self, a):  # (anything else goes to the plain packer, unshared)
+        return getattr(self._pk, a)
+
+
 class Packer:
     """fp32 OIHW / [out,in] master weights -> libupk packed fp16 (done once per weight set)."""
 
