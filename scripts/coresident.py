@@ -14,7 +14,7 @@ CFGS = sys.argv[2:] or ["1x7x4x1k4w3:1", "1x7x4x1k2w3:1", "4x2x2x2k2w3:1", "2x4x
 name = sys.argv[1] if len(sys.argv) > 1 else "c3_M8192"
 ks, cin, cout, H, W = SHAPES[name]
 B, NL = 8, 4
-R = 20 if H * W <= 1024 else 3
+R = int(os.environ.get("LAUNCHES", "0")) or (20 if H * W <= 1024 else 3)
 pool = LanePool(NL)
 print("streams on distinct queues:", pool.queue_probe)
 ctxs = [L.get_context(0, lane=i) for i in range(NL)]
@@ -27,7 +27,7 @@ for i in range(NL):
     x = torch.randn(B, H, W, cin, generator=g).half().cuda()
     w = (torch.randn(cout, cin, ks, ks, generator=g) / math.sqrt(K)).cuda()
     wp, n_pad = ctxs[i].pack_weight(w.contiguous())
-    wps = [wp.clone() for _ in range(8)]  # (cycled: cold weights, as inside the forward)
+    wps = [wp.clone() for _ in range(int(os.environ.get("WEIGHT_COPIES", "8")))]  # (cycled: cold weights, as inside the forward; 1 = warm)
     y = torch.zeros(B, H, W, cout, device="cuda", dtype=torch.float16)
     bias = torch.zeros(n_pad, device="cuda")
     sets.append((x, wps, y, bias, n_pad))
