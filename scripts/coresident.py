@@ -35,8 +35,13 @@ gf = 2.0 * B * H * W * cout * K / 1e9
 print("%s: k%d %d -> %d @%dx%d M=%d, %.2f GF per launch" % (name, ks, cin, cout, H, W, B * H * W, gf))
 
 
+SHARE = os.environ.get("SHARE_WEIGHTS", "0") == "1"  # every lane reads lane 0's weight copies (as the lanes of one model do)
+
+
 def graph(i, cfg, sk, stream):
     x, wps, y, bias, n_pad = sets[i]
+    if SHARE:
+        wps = sets[0][1]
     ctx = ctxs[i]
     ds = []
     for r in range(R):
