@@ -197,6 +197,17 @@ typedef struct upk_conv_desc {
    * launches with many M tiles per sample — the VAE decoder's 64x64 ... 256x256 feature maps — leave their partials
    * too; a consumer then folds them with upk_groupnorm_finalize_f32 before upk_groupnorm_apply_nhwc_f16 (mode 1). */
   int32_t gn_stats_cap;
+  /* Weight prefetch for the NEXT weight-consuming launch of this stream (round 6).  Inside the sampler
+   * loop every weight is cold when its launch starts: 0.85 GB of weights and ~2.7 GB of activations per forward pass
+   * through a 32 MB L2 and a 256 MB memory-side cache between two uses, and with several batches in flight a launch on
+   * cold weights costs 9-32 % more chip time than on warm ones (profiles/r06_weight_temperature_4_lanes.txt).  With
+   * pf_next != NULL the wave-specialised kernels' MFMA waves, idle while the first ring stage is in flight, touch one
+   * 16-byte piece of every 128-byte line of pf_next[0 .. pf_bytes) (direct-to-LDS loads into the dump row group: no
+   * registers, nothing to wait for), each workgroup its share: the lines are in the memory-side cache when the next
+   * launch — upk_conv_link_prefetch's caller passes the packed weight of the next conv / Linear — asks for them.  Other
+   * kernel families ignore the fields.  Purely a performance hint: results never depend on it. */
+  const void* pf_next;
+  int64_t pf_bytes;
 } upk_conv_desc;
 
 /* Replaces F.conv2d (3x3 s1/s2 p1, 1x1) / F.linear call sites:

@@ -198,13 +198,19 @@ elif MODE == "morelanes":
         plans = [lane_plan(i, s, 4) for i, s in enumerate(xs[:n])]
         print("%d lanes, full-mask streams (own queues)    : %.3f ms per forward" % (n, replay(plans, xs[:n])), flush=True)
 
-elif MODE == "knobs":
+elif MODE in ("knobs", "prefetch"):
     # row-chain kernels at the 16x16 level with the chip shared: 64-workgroup launches are what four lanes want
     from upgpt_amd import knobs
     pool = LanePool(4)
     streams = list(pool.streams)
-    for name, kv in (("default", {}), ("XBLOCK=1", {"XBLOCK": "1"}), ("MLP_FUSE=1", {"MLP_FUSE": "1"}), ("XBLOCK=1 MLP_FUSE=1", {"XBLOCK": "1", "MLP_FUSE": "1"}),
-                     ("XBLOCK=1 XB_ROWS=16", {"XBLOCK": "1", "XB_ROWS": 16}), ("default again", {})):
+    SETS = (("default", {}), ("XBLOCK=1", {"XBLOCK": "1"}), ("MLP_FUSE=1", {"MLP_FUSE": "1"}), ("XBLOCK=1 MLP_FUSE=1", {"XBLOCK": "1", "MLP_FUSE": "1"}),
+            ("XBLOCK=1 XB_ROWS=16", {"XBLOCK": "1", "XB_ROWS": 16}), ("default again", {}))
+    if MODE == "prefetch":  # next-weight prefetch (include/upk.h pf_next) off / on, and how much of the next weight
+        SETS = (("WEIGHT_PREFETCH=0", {"WEIGHT_PREFETCH": "0"}), ("WEIGHT_PREFETCH=1", {"WEIGHT_PREFETCH": "1"}),
+                ("WEIGHT_PREFETCH=0", {"WEIGHT_PREFETCH": "0"}), ("WEIGHT_PREFETCH=1", {"WEIGHT_PREFETCH": "1"}),
+                ("WEIGHT_PREFETCH=1 MAX=4MB", {"WEIGHT_PREFETCH": "1", "WEIGHT_PREFETCH_MAX": 4 << 20}),
+                ("WEIGHT_PREFETCH=1 MAX=1MB", {"WEIGHT_PREFETCH": "1", "WEIGHT_PREFETCH_MAX": 1 << 20}))
+    for name, kv in SETS:
         old = {k: getattr(knobs, k) for k in kv}
         for k, v in kv.items():
             setattr(knobs, k, v)
@@ -215,7 +221,11 @@ elif MODE == "knobs":
             plans = [lane_plan(i, s, 4) for i, s in enumerate(streams)]
             labs = [l for l in plans[0].body.labels if l.startswith(("xblock", "mlp", "hblock"))]
             ms = replay(plans, streams, reps=12)
-            print("%-24s %.3f ms per forward (%d kernels; row-chain ops: %s)" % (name, ms, len(plans[0].body.labels), sorted(set(labs))), flush=True)
+            if MODE == "prefetch":
+                one = replay(plans[:1], streams[:1], reps=12)
+                print("%-28s %.3f ms per forward in flight, %.3f ms one lane alone (%d prefetch links)" % (name, ms, one, plans[0].n_prefetch_links), flush=True)
+            else:
+                print("%-24s %.3f ms per forward (%d kernels; row-chain ops: %s)" % (name, ms, len(plans[0].body.labels), sorted(set(labs))), flush=True)
         except Exception as e:
             print("%-24s failed: %s" % (name, str(e)[:200]), flush=True)
         for k, v in old.items():

@@ -68,6 +68,7 @@ class ConvDesc(C.Structure):
         ("gno_silu", C.c_int32), ("gno_ld", C.c_int32), ("gno_skip_y", C.c_int32),
         ("ln_rows_out", C.c_void_p), ("ln_rows_in", C.c_void_p), ("ln_rows_slots", C.c_int32),
         ("w_phase", C.c_void_p), ("gn_stats_cap", C.c_int32),
+        ("pf_next", C.c_void_p), ("pf_bytes", C.c_int64),
     ]
 
 

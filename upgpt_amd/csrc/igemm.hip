@@ -529,6 +529,23 @@ __global__ __launch_bounds__(256 + LW * 64) void igemm_ws_kernel(const IgemmArgs
 
   // ================================ consumers ================================
   if (wave == 0) STAMP(0);
+  if (a.pf_lines > 0) {
+    // next launch's weights -> memory-side cache (include/upk.h pf_next): this workgroup's share of the lines, one 16-byte
+    // piece per line and lane, by direct-to-LDS loads into the dump row group.  The MFMA waves have nothing to do until ring
+    // stage 0 lands; the loads return whenever HBM answers and nobody waits for their data.
+    const int nwg = gridDim.x * gridDim.y * gridDim.z;
+    const int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int per = (a.pf_lines + nwg - 1) / nwg;
+    const int first = wg * per, last = min(a.pf_lines, first + per) - 1;
+    if (first <= last) {
+      typedef __attribute__((address_space(3))) void* lds_ptr;
+      typedef const __attribute__((address_space(1))) void* glb_ptr;
+      for (int l0 = first + wave * 64; l0 <= last; l0 += 256) {  // (wave-uniform trip count; lanes past the end re-touch the last line)
+        const int l = min(l0 + lane, last);
+        __builtin_amdgcn_global_load_lds((glb_ptr)(a.pf + (long)l * 128), (lds_ptr)(smem + NBUF * STAGE), 16, 0, 0);
+      }
+    }
+  }
   const int wm = KSPLIT ? 0 : wave / WN;
   const int wn = KSPLIT ? 0 : wave - wm * WN;
   const int lg = lane >> 4;
@@ -1278,6 +1295,8 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   a.ld1 = d->ld1;
   a.ld2 = d->ld2;
   a.w = (const f16*)d->w_packed;
+  a.pf = (const char*)d->pf_next;
+  a.pf_lines = d->pf_next && d->pf_bytes > 0 ? (int)((d->pf_bytes < (1ll << 37) ? d->pf_bytes : (1ll << 37)) >> 7) : 0;  // (whole lines only)
   a.zero = (const f16*)ctx->zero_page;
   a.npad = d->n_pad;
   a.bias = d->bias;

@@ -90,6 +90,9 @@ struct IgemmArgs {
   // ---- A-stationary family (astat.hip): a workgroup keeps its BM x K activation tile in LDS and walks passes
   // [tn * as_ppw, min(as_npass, (tn + 1) * as_ppw)) of 8 waves x NI x 16 output columns; tiles_n = N super tiles
   int as_ppw, as_npass;
+  // ---- next-weight prefetch (include/upk.h pf_next): lines of pf[0 .. pf_lines * 128) are touched by this launch's workgroups
+  const char* pf;
+  int pf_lines;
 };
 
 // Split-K partial slabs ([split][M][n_pad] in the caller's workspace, IgemmArgs::partial).  fp16: the partial sums are

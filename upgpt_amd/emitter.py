@@ -123,6 +123,25 @@ class Emitter:
             cache.save(os.environ["UPGPT_TUNE_SAVE"])
         return hits, tuned, missing
 
+    def link_weight_prefetch(self, prog, wrap=True):
+        """Every conv / Linear launch of `prog` is told the packed weight of the NEXT one (include/upk.h pf_next): its
+        idle MFMA waves pull those lines into the memory-side cache while their own first ring stage is in flight, so the next
+        launch does not start on cold weights (UPGPT_WEIGHT_PREFETCH=0 switches it off, =2 also when one
+        batch has the chip to itself).  wrap: the last launch prefetches for the first one — the program is replayed step
+        after step.  Returns the number of links."""
+        mode = K.WEIGHT_PREFETCH
+        if mode == "0" or (mode == "auto" and L.concurrency() <= 1):
+            return 0
+        ds = [d for d in prog.meta if d is not None and getattr(d, "_w_bytes", 0)]
+        n = 0
+        for i, d in enumerate(ds):
+            nxt = ds[i + 1] if i + 1 < len(ds) else (ds[0] if wrap and len(ds) > 1 else None)
+            if nxt is None or nxt.w_packed == d.w_packed:
+                continue
+            d.pf_next, d.pf_bytes = nxt.w_packed, min(nxt._w_bytes, K.WEIGHT_PREFETCH_MAX)
+            n += 1
+        return n
+
     def _is_as(self, cfg):
         """Whether configuration `cfg` belongs to the A-stationary family (their second tuning slot is output-column
         passes per workgroup, not a split-K factor)."""
@@ -259,6 +278,7 @@ class Emitter:
         d.batch, d.in_h, d.in_w = B, H, W
         d.ksize, d.stride = ks, stride
         d.w_packed = pw.w.data_ptr()
+        d._w_bytes = int(pw.w.numel()) * 2  # (host-side note for link_weight_prefetch; not part of the C struct)
         d.n_out, d.n_pad = pw.n_out, pw.n_pad
         if pw.bias is not None:
             d.bias = pw.bias.data_ptr()

@@ -62,6 +62,7 @@ class UNetPlan(Emitter):
         self.body = Program(ctx)
         self._emit_prep()
         self._emit_body()
+        self.n_prefetch_links = self.link_weight_prefetch(self.body)
 
     # ---- step-invariant part
     def _emit_prep(self):
