@@ -32,13 +32,30 @@ while w < t1:
         fw = sum(1 for _, _, d, _, s0 in sel if d and s0 >= w)  # (a forward belongs to the window its step kernel starts in)
         wins.append(dict(start_ms=(w - t0) / 1e6, kernels=len(sel), sum_ms=ssum / 1e6, gemm_sum_ms=gsum / 1e6, union_ms=union / 1e6, forwards=fw, busy=union / W))
     w += W
-steady = [x for x in wins if x["busy"] >= 0.9 and x["forwards"] > 0]
-res = {"gflop_per_forward": GF, "peak_tflops": PEAK / 1e12, "window_ms": W / 1e6, "windows": len(wins), "steady_windows": len(steady)}
+# the bench command runs the steps one batch at a time first (`serial`: one kernel at a time, sum of durations ~ union), then with
+# the lanes in flight (sum / union ~ 3): the two phases are told apart by that ratio, window by window
+busy = [x for x in wins if x["busy"] >= 0.9 and x["forwards"] > 0]
+steady = [x for x in busy if x["sum_ms"] / x["union_ms"] >= 1.5]
+serial = [x for x in busy if x["sum_ms"] / x["union_ms"] < 1.2]
+res = {"gflop_per_forward": GF, "peak_tflops": PEAK / 1e12, "window_ms": W / 1e6, "windows": len(wins), "steady_windows": len(steady),
+       "serial_windows": len(serial)}
+
+
+def phase(sel):
+    fw = sum(x["forwards"] for x in sel)
+    un = sum(x["union_ms"] for x in sel)
+    ss = sum(x["sum_ms"] for x in sel)
+    return {"forwards": fw, "union_busy_ms": un, "sum_of_kernel_durations_ms": ss, "kernels_running_while_busy": ss / un,
+            "union_ms_per_forward": un / fw, "frac_from_trace": fw * GF * 1e9 / (un * 1e-3) / PEAK}
+
+
 if steady:
-    fw = sum(x["forwards"] for x in steady); un = sum(x["union_ms"] for x in steady); ss = sum(x["sum_ms"] for x in steady)
-    res.update({"forwards": fw, "union_busy_ms": un, "sum_of_kernel_durations_ms": ss, "kernels_running_while_busy": ss / un,
-                "union_ms_per_forward": un / fw, "frac_from_trace": fw * GF * 1e9 / (un * 1e-3) / PEAK,
-                "note": "all kernels of the windows count as busy time (VAE decode, layout converts and the gather included), only UNet FLOPs count as work"})
+    res.update(phase(steady))
+    res["note"] = ("windows with the lanes in flight (device busy >= 90 %, sum of kernel durations / union >= 1.5); all their kernels "
+                   "count as busy time (VAE decode, layout converts and the gather included), only UNet FLOPs count as work; the "
+                   "run is slower under the tracer than the untraced bench line (per-dispatch profiler overhead)")
+if serial:
+    res["serial_phase"] = phase(serial)
 json.dump(res, open(out_json, "w"), indent=1)
 with open(out_txt, "w") as f:
     f.write("# %s\n# window_start_ms kernels sum_of_durations_ms conv_gemm_sum_ms union_busy_ms forwards busy_share\n" % json.dumps({k: v for k, v in res.items() if k != "note"}))
