@@ -208,8 +208,8 @@ elif MODE in ("knobs", "prefetch"):
     if MODE == "prefetch":  # next-weight prefetch (include/upk.h pf_next) off / on, and how much of the next weight
         SETS = (("WEIGHT_PREFETCH=0", {"WEIGHT_PREFETCH": "0"}), ("WEIGHT_PREFETCH=1", {"WEIGHT_PREFETCH": "1"}),
                 ("WEIGHT_PREFETCH=0", {"WEIGHT_PREFETCH": "0"}), ("WEIGHT_PREFETCH=1", {"WEIGHT_PREFETCH": "1"}),
-                ("WEIGHT_PREFETCH=1 MAX=4MB", {"WEIGHT_PREFETCH": "1", "WEIGHT_PREFETCH_MAX": 4 << 20}),
-                ("WEIGHT_PREFETCH=1 MAX=1MB", {"WEIGHT_PREFETCH": "1", "WEIGHT_PREFETCH_MAX": 1 << 20}))
+                ("WEIGHT_PREFETCH=1 AHEAD=2", {"WEIGHT_PREFETCH": "1", "WEIGHT_PREFETCH_AHEAD": 2}),
+                ("WEIGHT_PREFETCH=1 AHEAD=3", {"WEIGHT_PREFETCH": "1", "WEIGHT_PREFETCH_AHEAD": 3}))
     for name, kv in SETS:
         old = {k: getattr(knobs, k) for k in kv}
         for k, v in kv.items():
@@ -223,7 +223,13 @@ elif MODE in ("knobs", "prefetch"):
             ms = replay(plans, streams, reps=12)
             if MODE == "prefetch":
                 one = replay(plans[:1], streams[:1], reps=12)
-                print("%-28s %.3f ms per forward in flight, %.3f ms one lane alone (%d prefetch links)" % (name, ms, one, plans[0].n_prefetch_links), flush=True)
+                for pl in list(unet._plans.values()):
+                    pl.close()
+                unet._plans.clear()
+                ser = lane_plan(0, streams[0], 1)  # the latency table: one forward with the chip to itself (`serial`)
+                lat = replay([ser], streams[:1], reps=12)
+                print("%-28s %.3f ms per forward in flight, %.3f ms one lane alone; latency table alone %.3f ms (%d prefetch links)" % (
+                    name, ms, one, lat, ser.n_prefetch_links), flush=True)
             else:
                 print("%-24s %.3f ms per forward (%d kernels; row-chain ops: %s)" % (name, ms, len(plans[0].body.labels), sorted(set(labs))), flush=True)
         except Exception as e:

@@ -134,8 +134,10 @@ class Emitter:
             return 0
         ds = [d for d in prog.meta if d is not None and getattr(d, "_w_bytes", 0)]
         n = 0
+        ahead = max(1, K.WEIGHT_PREFETCH_AHEAD)
         for i, d in enumerate(ds):
-            nxt = ds[i + 1] if i + 1 < len(ds) else (ds[0] if wrap and len(ds) > 1 else None)
+            j = i + ahead
+            nxt = ds[j] if j < len(ds) else (ds[j % len(ds)] if wrap and len(ds) > ahead else None)
             if nxt is None or nxt.w_packed == d.w_packed:
                 continue
             d.pf_next, d.pf_bytes = nxt.w_packed, min(nxt._w_bytes, K.WEIGHT_PREFETCH_MAX)

@@ -30,5 +30,6 @@ HBLOCK_GN = os.environ.get("UPGPT_HBLOCK_GN", "1") == "1"  # SpatialTransformer.
 # next-weight prefetch (include/upk.h pf_next, Emitter.link_weight_prefetch): "auto" = while several batches share the chip
 # (where cold weights cost 9-32 % per launch), "0" off, "1" always
 WEIGHT_PREFETCH = os.environ.get("UPGPT_WEIGHT_PREFETCH", "auto")
+WEIGHT_PREFETCH_AHEAD = int(os.environ.get("UPGPT_WEIGHT_PREFETCH_AHEAD", "1"))  # which following launch's weight: 1 = the next
 WEIGHT_PREFETCH_MAX = int(os.environ.get("UPGPT_WEIGHT_PREFETCH_MAX", str(32 << 20)))  # bytes of the next weight at most
 LN_LAUNCH_US = 5.0  # what a separate LayerNorm launch costs inside the replayed forward (3.8 us of kernel + its boundary: DESIGN.md 11i / 11j)
