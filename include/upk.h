@@ -199,8 +199,9 @@ typedef struct upk_conv_desc {
   int32_t gn_stats_cap;
   /* Weight prefetch for the NEXT weight-consuming launch of this stream (round 6).  Inside the sampler
    * loop every weight is cold when its launch starts: 0.85 GB of weights and ~2.7 GB of activations per forward pass
-   * through a 32 MB L2 and a 256 MB memory-side cache between two uses, and with several batches in flight a launch on
-   * cold weights costs 9-32 % more chip time than on warm ones (profiles/r06_weight_temperature_4_lanes.txt).  With
+   * through a 32 MB L2 and a 256 MB memory-side cache between two uses (a launch on cold weights costs 9-32 % more than on
+   * warm ones, profiles/r06_weight_temperature_4_lanes.txt).  Measured (profiles/r06_next_weight_prefetch.txt): one forward
+   * alone 2.83 -> 2.76 ms, with four forwards in flight 1.461 -> 1.471 ms — the host arms it only for the former.  With
    * pf_next != NULL the wave-specialised kernels' MFMA waves, idle while the first ring stage is in flight, touch one
    * 16-byte piece of every 128-byte line of pf_next[0 .. pf_bytes) (direct-to-LDS loads into the dump row group: no
    * registers, nothing to wait for), each workgroup its share: the lines are in the memory-side cache when the next

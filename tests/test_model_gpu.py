@@ -737,3 +737,36 @@ def test_sampler_advances_the_generator_like_the_reference():
         for _ in range(1 + ndraw):
             torch.randn(shape, device="cuda")
         assert torch.equal(after, torch.randn(8, device="cuda")), type(sampler).__name__
+
+
+def test_next_weight_prefetch_is_a_hint_results_are_bit_identical(monkeypatch):
+    """include/upk.h pf_next (Emitter.link_weight_prefetch): every conv / Linear launch of the step program touches the packed
+    weight of the next one.  Purely a performance hint: eps and a 4-step sample are bit-identical with it off and on, the
+    links cover the body's launches and wrap around (the program is replayed step after step)."""
+    from upgpt_amd import knobs
+    model, _ = get_model("tiny")
+    unet = model.model.diffusion_model
+    inp = inputs("tiny", 2)
+    cond = {"c_crossattn": inp["c_crossattn"].cuda(), "c_concat": [inp["c_concat"].cuda()]}
+    x_T = inp["x_T"].cuda()
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setattr(knobs, "WEIGHT_PREFETCH", mode)
+        for pl in list(unet._plans.values()):
+            pl.close()
+        unet._plans.clear()
+        eps = model.apply_model(x_T, torch.tensor([981, 981]).cuda(), cond)
+        z = DDIMSampler(model).sample(4, 2, (4, 32, 24), cond, eta=0.0, x_T=x_T, verbose=False)[0]
+        plans = list(unet._plans.values())
+        outs[mode] = (eps.clone(), z.clone(), [p.n_prefetch_links for p in plans])
+        if mode == "1":
+            for p in plans:
+                ds = [d for d in p.body.meta if d is not None]
+                assert p.n_prefetch_links >= len(ds) - 2 and all(d.pf_bytes >= 0 for d in ds)
+                linked = [d for d in ds if d.pf_next]
+                assert linked and all(d.pf_next != d.w_packed and d.pf_bytes % 2 == 0 for d in linked)
+    assert outs["0"][2] and all(n == 0 for n in outs["0"][2])
+    assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])
+    for pl in list(unet._plans.values()):
+        pl.close()
+    unet._plans.clear()
