@@ -28,7 +28,8 @@ XB_ROWS = int(os.environ.get("UPGPT_XB_ROWS", "0"))  # rows per workgroup (16 / 
 HBLOCK = os.environ.get("UPGPT_HBLOCK", "auto")
 HBLOCK_GN = os.environ.get("UPGPT_HBLOCK_GN", "1") == "1"  # SpatialTransformer.norm applied on the tile inside that launch
 # next-weight prefetch (include/upk.h pf_next, Emitter.link_weight_prefetch): "auto" = while one batch has the chip to itself
-# (forward 2.83 -> 2.76 ms; with four forwards in flight 1.461 -> 1.471 ms per forward: off there), "0" off, "1" always
+# (replayed forward 2.83 -> 2.76 ms, serial bench 53.28 -> 53.61 images/s in same-box pairs; with four forwards in flight
+# 1.461 -> 1.471 ms per forward: off there), "0" off, "1" always
 WEIGHT_PREFETCH = os.environ.get("UPGPT_WEIGHT_PREFETCH", "auto")
 WEIGHT_PREFETCH_AHEAD = int(os.environ.get("UPGPT_WEIGHT_PREFETCH_AHEAD", "1"))  # which following launch's weight: 1 = the next
 WEIGHT_PREFETCH_MAX = int(os.environ.get("UPGPT_WEIGHT_PREFETCH_MAX", str(32 << 20)))  # bytes of the next weight at most
