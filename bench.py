@@ -726,6 +726,20 @@ def main():
                 dt2l, _ = timed_lanes(pool, step2, k2, dev)
             cfg_true_lanes = {"value": args.batch * k2 / dt2l, "unit": "images/s", "steps": k2, "batches_in_flight_per_gpu": n_lanes}
             del wls2
+            # control: the same lanes with TWICE the batch per forward.  Not the configuration BASELINE.json
+            # names (bs = 8 per GPU and forward) and never `value`: it shows what the path gives when a caller can batch 16
+            wls16 = [Workload(model, 2 * args.batch, hw, args.ddim_steps, seed=rank + 1000 * l + 7) for l in range(n_lanes)]
+            step16 = lambda k: wls16[k % n_lanes].run()
+            k16 = 2 * n_lanes
+            with contextlib.redirect_stdout(io.StringIO()):
+                timed_lanes(pool, step16, 2 * n_lanes, dev)
+                dt16, _ = timed_lanes(pool, step16, k16, dev)
+            result["control_batch16_per_forward"] = {
+                "value": 2 * args.batch * k16 / dt16, "unit": "images/s", "batch_per_forward": 2 * args.batch, "steps": k16,
+                "batches_in_flight_per_gpu": n_lanes,
+                "note": "control, not the headline: %d lanes x bs = %d per sample() call (UNet forward + decode at twice the batch); "
+                        "`value` stays at bs = %d per forward" % (n_lanes, 2 * args.batch, args.batch)}
+            del wls16
         # everything below describes ONE forward with the chip to itself (the launch choices tuned for that case): kernel
         # quality in isolation, comparable with the earlier rounds' lines
         from upgpt_amd import _lib as _L
