@@ -237,6 +237,18 @@ elif MODE in ("knobs", "prefetch"):
         for k, v in old.items():
             setattr(knobs, k, v)
 
+elif MODE == "fwd":
+    # the three forward times of the current environment (A/B of library-level switches, one process per setting)
+    pool = LanePool(4)
+    streams = list(pool.streams)
+    plans = [lane_plan(i, s, 4) for i, s in enumerate(streams)]
+    ms = replay(plans, streams, reps=12)
+    one = replay(plans[:1], streams[:1], reps=12)
+    ser = lane_plan(0, streams[0], 1)
+    lat = replay([ser], streams[:1], reps=12)
+    print("%s: %.3f ms per forward in flight, %.3f ms one lane alone; latency table alone %.3f ms" % (
+        os.environ.get("LAB_TAG", ""), ms, one, lat), flush=True)
+
 elif MODE == "clock":
     # shader clock under load: a spinning probe wave on a fifth stream while 0 / 1 / 4 lanes replay forwards
     pool = LanePool(4)

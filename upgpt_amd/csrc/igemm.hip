@@ -529,6 +529,32 @@ __global__ __launch_bounds__(256 + LW * 64) void igemm_ws_kernel(const IgemmArgs
 
   // ================================ consumers ================================
   if (wave == 0) STAMP(0);
+  if (a.pf_self) {
+    // (experiment) this launch's OWN weight slice -> this XCD's L2, cooperatively: the workgroups of an XCD that
+    // share the (N tile, K split) slice each touch every cnt-th chunk of it up front, so that the slice is requested from HBM
+    // through cnt CUs' load windows at once instead of through each CU's own ~64 KB window, chunk after chunk
+    int rank, cnt;
+    if (a.xm_pm == 0) {  // default tile order: workgroup w = tile index runs on XCD w % 8, M tiles fastest
+      cnt = max(1, a.tiles_m >> 3);
+      rank = (tm >> 3) % cnt;
+    } else {
+      cnt = max(1, a.xm_mi);
+      rank = (int)(blockIdx.x >> 3) % cnt;
+    }
+    const int lpc = BN / 2;  // 128-byte lines of one chunk's BN x 64 B block
+    const int mine = (kc1 - kc0 - rank + cnt - 1) / cnt;  // chunks kc0 + rank, + cnt, ...
+    const int total = mine * lpc;
+    const int lines_ok = min(BN, a.npad - n0) / 2;  // (rows past n_pad do not exist)
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const f16* wb = a.w + (long)ph * a.ph_wstride + ((long)kc0 * a.npad + n0) * 32;
+    for (int l0 = wave * 64; l0 < total; l0 += 256) {
+      const int l = min(l0 + lane, total - 1);
+      const int ci = l / lpc, li = min(l - ci * lpc, lines_ok - 1);
+      const f16* src = wb + ((long)(rank + ci * cnt) * a.npad) * 32 + li * 64;
+      __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(smem + NBUF * STAGE), 16, 0, 0);
+    }
+  }
   if (a.pf_lines > 0) {
     // next launch's weights -> memory-side cache (include/upk.h pf_next): this workgroup's share of the lines, one 16-byte
     // piece per line and lane, by direct-to-LDS loads into the dump row group.  The MFMA waves have nothing to do until ring
@@ -1295,6 +1321,8 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   a.ld1 = d->ld1;
   a.ld2 = d->ld2;
   a.w = (const f16*)d->w_packed;
+  static const int self_pf = getenv("UPK_SELF_PREFETCH") ? atoi(getenv("UPK_SELF_PREFETCH")) : 0;
+  a.pf_self = self_pf;
   a.pf = (const char*)d->pf_next;
   a.pf_lines = d->pf_next && d->pf_bytes > 0 ? (int)((d->pf_bytes < (1ll << 37) ? d->pf_bytes : (1ll << 37)) >> 7) : 0;  // (whole lines only)
   a.zero = (const f16*)ctx->zero_page;

@@ -93,6 +93,7 @@ struct IgemmArgs {
   // ---- next-weight prefetch (include/upk.h pf_next): lines of pf[0 .. pf_lines * 128) are touched by this launch's workgroups
   const char* pf;
   int pf_lines;
+  int pf_self;  // (dev experiment, UPK_SELF_PREFETCH=1: the workgroups of an XCD that share a weight slice touch it cooperatively up front)
 };
 
 // Split-K partial slabs ([split][M][n_pad] in the caller's workspace, IgemmArgs::partial).  fp16: the partial sums are
