@@ -1321,8 +1321,6 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   a.ld1 = d->ld1;
   a.ld2 = d->ld2;
   a.w = (const f16*)d->w_packed;
-  static const int self_pf = getenv("UPK_SELF_PREFETCH") ? atoi(getenv("UPK_SELF_PREFETCH")) : 0;
-  a.pf_self = self_pf;
   a.pf = (const char*)d->pf_next;
   a.pf_lines = d->pf_next && d->pf_bytes > 0 ? (int)((d->pf_bytes < (1ll << 37) ? d->pf_bytes : (1ll << 37)) >> 7) : 0;  // (whole lines only)
   a.zero = (const f16*)ctx->zero_page;
@@ -1510,6 +1508,14 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   a.tiles_n = is_as ? aspl.tiles_n : cdiv(a.npad, BN);
   a.chunks_per_split = cdiv(a.nchunks, best_sk);
   const int zdim = cdiv(a.nchunks, a.chunks_per_split);
+  {
+    // (dev experiment) cooperative up-front touch of the launch's own weight slices: 0 off, 1 every wave-specialised
+    // launch, 2 only where a slice is shared by few M tiles and is large (the 16x16 and deeper levels), 3 = 2 with lanes only
+    static const int self_pf = getenv("UPK_SELF_PREFETCH") ? atoi(getenv("UPK_SELF_PREFETCH")) : 0;
+    static const int self_tm = getenv("UPK_SELF_PREFETCH_TM") ? atoi(getenv("UPK_SELF_PREFETCH_TM")) : 32;
+    const long slice = (long)BN * 64 * a.chunks_per_split;
+    a.pf_self = self_pf == 1 || (self_pf >= 2 && a.tiles_m <= self_tm && slice >= (256 << 10));
+  }
   a.partial = (zdim > 1) ? (float*)ctx->ws : nullptr;
   // GroupNorm partials from the reduce pass (see igemm_reduce_gn_kernel)
   // ... or the whole GroupNorm from the reduce pass (igemm_reduce_gnapply_kernel)
