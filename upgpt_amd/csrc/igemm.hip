@@ -529,8 +529,9 @@ __global__ __launch_bounds__(256 + LW * 64) void igemm_ws_kernel(const IgemmArgs
 
   // ================================ consumers ================================
   if (wave == 0) STAMP(0);
+#ifdef UPK_R6_EXPERIMENTS
   if (a.pf_self) {
-    // (experiment) this launch's OWN weight slice -> this XCD's L2, cooperatively: the workgroups of an XCD that
+    // (experiment, DESIGN.md 14h: dev builds only — it loses with four forwards in flight and on the latency table) this launch's OWN weight slice -> this XCD's L2, cooperatively: the workgroups of an XCD that
     // share the (N tile, K split) slice each touch every cnt-th chunk of it up front, so that the slice is requested from HBM
     // through cnt CUs' load windows at once instead of through each CU's own ~64 KB window, chunk after chunk
     int rank, cnt;
@@ -555,6 +556,7 @@ __global__ __launch_bounds__(256 + LW * 64) void igemm_ws_kernel(const IgemmArgs
       __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)(smem + NBUF * STAGE), 16, 0, 0);
     }
   }
+#endif
   if (a.pf_lines > 0) {
     // next launch's weights -> memory-side cache (include/upk.h pf_next): this workgroup's share of the lines, one 16-byte
     // piece per line and lane, by direct-to-LDS loads into the dump row group.  The MFMA waves have nothing to do until ring
@@ -1508,6 +1510,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   a.tiles_n = is_as ? aspl.tiles_n : cdiv(a.npad, BN);
   a.chunks_per_split = cdiv(a.nchunks, best_sk);
   const int zdim = cdiv(a.nchunks, a.chunks_per_split);
+#ifdef UPK_R6_EXPERIMENTS
   {
     // (dev experiment) cooperative up-front touch of the launch's own weight slices: 0 off, 1 every wave-specialised
     // launch, 2 only where a slice is shared by few M tiles and is large (the 16x16 and deeper levels), 3 = 2 with lanes only
@@ -1516,6 +1519,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     const long slice = (long)BN * 64 * a.chunks_per_split;
     a.pf_self = self_pf == 1 || (self_pf >= 2 && a.tiles_m <= self_tm && slice >= (256 << 10));
   }
+#endif
   a.partial = (zdim > 1) ? (float*)ctx->ws : nullptr;
   // GroupNorm partials from the reduce pass (see igemm_reduce_gn_kernel)
   // ... or the whole GroupNorm from the reduce pass (igemm_reduce_gnapply_kernel)
