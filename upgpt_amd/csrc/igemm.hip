@@ -437,14 +437,14 @@ __global__ __launch_bounds__(256 + LW * 64) void igemm_ws_kernel(const IgemmArgs
 #pragma unroll
         for (int i = 0; i < AGW; ++i) {
           const int rg = lw + LW * i;  // wave-uniform
-          const f16* src = (live && tap_ok[i]) ? ((second ? ap2[i] : ap1[i]) + cur_c0) : zsrc;
+          const f16* src = (live && tap_ok[i] && !ABL_ON(ABL_NOA)) ? ((second ? ap2[i] : ap1[i]) + cur_c0) : zsrc;
           f16* dst = (rg < AG) ? base + (s * ROWS + rg * 16) * 32 : smem + NBUF * STAGE;
           __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)dst, 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < BGW; ++i) {
           const int rg = lw + LW * i;
-          const f16* src = (live && b_ok[i]) ? bp[i] : zsrc;
+          const f16* src = (live && b_ok[i] && !ABL_ON(ABL_NOB)) ? bp[i] : zsrc;
           f16* dst = (rg < BG) ? base + (s * ROWS + BM + rg * 16) * 32 : smem + NBUF * STAGE;
           // (nt on the weight stream of the split-K launches — each line read once by one or two workgroups — measured
           // +70 us on the forward, 2.946 -> 3.015 ms: the slices ARE shared across the XCD's M tiles through L2)
@@ -1423,7 +1423,7 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
     a.nchunks += (a.c3 + a.c4) / 32;
   }
   a.flags = flags;
-  if (const char* ab = getenv("UPK_ABLATE")) a.flags |= (int)strtol(ab, nullptr, 0) & 0x3FF0000;
+  if (const char* ab = getenv("UPK_ABLATE")) a.flags |= (int)strtol(ab, nullptr, 0) & 0xFFF0000;
   a.dbg = (unsigned long long*)((char*)ctx->ws + ctx->ws_bytes - 4096);
 
   // ---- choose config + split-K ----

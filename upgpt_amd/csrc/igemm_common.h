@@ -18,6 +18,8 @@ enum {
   ABL_NOGNP = 0x800000,     // plain epilogue: no GroupNorm channel partials (column sums, LDS exchange, their stores)
   ABL_NOEPILD = 0x1000000,  // plain epilogue: operands (bias, row vector, residual) read as zeros, no loads
   ABL_NOSLAB = 0x2000000,   // split-K launches: the partial slabs (fp16, fp32 with -DUPK_SLAB_F32) are not written
+  ABL_NOA = 0x4000000,      // WS loaders: every A (im2col) row group fetches the zero page — the requests stay, their lines do not
+  ABL_NOB = 0x8000000,      // WS loaders: every B (weight) row group fetches the zero page
 };
 // The ablation / timeline hooks are compiled in only for dev builds (UPK_CXXFLAGS=-DUPK_DEV, scripts/ablate.sh,
 // scripts/timeline*.py): even as never-taken runtime tests they cost scalar registers and instructions in the loops.
