@@ -171,11 +171,11 @@ class CLIPVisual(ParamTree):
                         torch.cuda.current_stream(p.device).synchronize()  # (packed on this lane's stream, read from every lane's)
         import contextlib
         from ._lib import host_io
-        with torch.cuda.device(p.device):
-            # only the upload of crops that live on the host is serialised against other lanes' graph captures; the tower
-            # itself (eager launches on this lane's stream) overlaps with whatever the other lanes run
-            with (host_io() if not images.is_cuda else contextlib.nullcontext()):
-                plan.upload(images)
+        with torch.cuda.device(p.device), host_io():
+            # the whole tower stays serialised against the other lanes' graph captures: with only the upload under the lock
+            #  the secondary bench hit "capturing stream has unjoined work" once in five sessions — a tower's first
+            # eager launches set function attributes and allocate while another lane captures.  Packed weights are shared.
+            plan.upload(images)
             return plan.execute()
 
 

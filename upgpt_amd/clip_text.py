@@ -218,9 +218,9 @@ class _TextTower(ParamTree):
         from ._lib import host_io
         with torch.cuda.device(p.device):
             plan.check(input_ids)
-            with host_io():  # (token ids / end-of-text rows come from the host: only the upload is serialised, _lib.host_io)
+            with host_io():  # (token ids come from the host; the tower's eager launches stay under the lock too: clip_image.py)
                 plan.upload(input_ids)
-            return plan.execute()  # (eager launches on this lane's stream: overlaps with the other lanes)
+                return plan.execute()
 
 
 class CLIPTextTransformer(_TextTower):
