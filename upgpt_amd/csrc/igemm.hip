@@ -402,55 +402,28 @@ __global__ __launch_bounds__(256 + LW * 64) void igemm_ws_kernel(const IgemmArgs
       ctot = a.c3 + a.c4;
       set_tap(a.pad_lo, a.pad_lo);
     };
+    if (APP && kc0 >= a.nchunks_main) {
+      cur_c0 = (kc0 - a.nchunks_main) * 32;
+      cur_ky = cur_kx = 0;
+      enter_append();
+    } else {
+      const int tap = kc0 / a.cpt;
+      cur_c0 = (kc0 - tap * a.cpt) * 32;
+      cur_ky = tap / a.ks;
+      cur_kx = tap - cur_ky * a.ks;
+      set_tap(cur_ky, cur_kx);
+    }
     // B rows of this lane
     const f16* bp[BGW];
     bool b_ok[BGW];
 #pragma unroll
     for (int i = 0; i < BGW; ++i) {
       const int rg = lw + LW * i;
-      b_ok[i] = (rg < BG) && (n0 + rg * 16 + r16 < a.npad);
+      const int row = rg * 16 + r16;
+      b_ok[i] = (rg < BG) && (n0 + row < a.npad);
+      bp[i] = a.w + (long)ph * a.ph_wstride + ((long)kc0 * a.npad + n0 + row) * 32 + chd * 8;
     }
     const long wstep = (long)a.npad * 32;
-    // positions the cursor (tap, channel offset, source pair, weight rows) on K chunk kc of this workgroup's range
-    auto seek = [&](int kc) {
-      cur_kc = kc;
-      if (APP && kc >= a.nchunks_main) {
-        cur_c0 = (kc - a.nchunks_main) * 32;
-        cur_ky = cur_kx = 0;
-        enter_append();
-      } else {
-        in_app = false;
-        sc1 = a.c1;
-        ctot = a.c1 + a.c2;
-        const int tap = kc / a.cpt;
-        cur_c0 = (kc - tap * a.cpt) * 32;
-        cur_ky = tap / a.ks;
-        cur_kx = tap - cur_ky * a.ks;
-        set_tap(cur_ky, cur_kx);
-      }
-#pragma unroll
-      for (int i = 0; i < BGW; ++i)
-        bp[i] = a.w + (long)ph * a.ph_wstride + ((long)kc * a.npad + n0 + (lw + LW * i) * 16 + r16) * 32 + chd * 8;
-    };
-    int kstart = kc0;
-#ifdef UPK_R6_EXPERIMENTS
-    if (a.krot) {
-      // (experiment) the workgroups of an XCD that share this (N tile, K split) weight slice run in lock step and
-      // wait for the same cold line together; walking the K range from staggered starts (wrapping around) makes each of them
-      // the first toucher of 1 / cnt of the slice and finds the rest in the L2 — no extra request, only another summation order
-      int rank, cnt;
-      if (a.xm_pm == 0) {
-        cnt = max(1, a.tiles_m >> 3);
-        rank = (tm >> 3) % cnt;
-      } else {
-        cnt = max(1, a.xm_mi);
-        rank = (int)(blockIdx.x >> 3) % cnt;
-      }
-      kstart = kc0 + (int)(((long)(kc1 - kc0) * rank) / cnt);
-    }
-#endif
-    int left = kc1 - kc0;  // chunks still to issue (the walk wraps from kc1 to kc0 when it did not start at kc0)
-    seek(kstart);
 
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
@@ -459,7 +432,7 @@ __global__ __launch_bounds__(256 + LW * 64) void igemm_ws_kernel(const IgemmArgs
       f16* base = smem + slot * STAGE;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const bool live = left > 0;
+        const bool live = cur_kc < kc1;
         const bool second = cur_c0 >= sc1;
 #pragma unroll
         for (int i = 0; i < AGW; ++i) {
@@ -479,17 +452,14 @@ __global__ __launch_bounds__(256 + LW * 64) void igemm_ws_kernel(const IgemmArgs
           bp[i] += wstep;
         }
         ++cur_kc;
-        --left;
         cur_c0 += 32;
-        if (cur_kc == kc1 && left > 0) {
-          seek(kc0);  // (rotated walk: wrap around)
-        } else if (cur_c0 == ctot) {
+        if (cur_c0 == ctot) {
           cur_c0 = 0;
           if (++cur_kx == a.ks) {
             cur_kx = 0;
             ++cur_ky;
           }
-          if (left > 0) {
+          if (cur_kc < kc1) {
             if (APP && cur_kc == a.nchunks_main) enter_append();
             else set_tap(cur_ky, cur_kx);
           }
@@ -1541,10 +1511,6 @@ static int conv_impl(upk_ctx* ctx, const upk_conv_desc* d, upk_stream stream_, b
   a.chunks_per_split = cdiv(a.nchunks, best_sk);
   const int zdim = cdiv(a.nchunks, a.chunks_per_split);
 #ifdef UPK_R6_EXPERIMENTS
-  {
-    static const int krot = getenv("UPK_KROT") ? atoi(getenv("UPK_KROT")) : 0;
-    a.krot = krot;
-  }
   {
     // (dev experiment) cooperative up-front touch of the launch's own weight slices: 0 off, 1 every wave-specialised
     // launch, 2 only where a slice is shared by few M tiles and is large (the 16x16 and deeper levels), 3 = 2 with lanes only

@@ -95,7 +95,6 @@ struct IgemmArgs {
   // ---- next-weight prefetch (include/upk.h pf_next): lines of pf[0 .. pf_lines * 128) are touched by this launch's workgroups
   const char* pf;
   int pf_lines;
-  int krot;     // (dev experiment, UPK_KROT=1: staggered K walk of the workgroups that share a weight slice)
   int pf_self;  // (dev experiment, UPK_SELF_PREFETCH=1: the workgroups of an XCD that share a weight slice touch it cooperatively up front)
 };
 
