@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs the dev library: UPK_LIB=$PWD/upgpt_amd/libupk_dev.so UPK_CXXFLAGS=-DUPK_DEV python -m upgpt_amd.build (built here, ships with the snapshot)
 # Round 6: what do the operand fetches cost with four chains in flight?  Dev build (-DUPK_DEV): the wave-specialised loaders fetch
 # the zero page instead of the A (im2col) rows / the B (weight) rows / both — the DMA instructions stay, their lines do not
 # (results are garbage, times are not).  Upper bound of what a halo-resident A operand (A bytes / 5.6) could give.

@@ -1,4 +1,6 @@
 #!/bin/bash
+# needs the experiments library built from commit e4f4ad5 (the staggered walk is not in the tree any more):
+#   UPK_LIB=$PWD/upgpt_amd/libupk_exp.so UPK_CXXFLAGS=-DUPK_R6_EXPERIMENTS python -m upgpt_amd.build
 # Round 6: staggered K walk (UPK_KROT, -DUPK_R6_EXPERIMENTS build): op tests both ways, chip time per launch on cold weights, the
 # three forward times.
 mkdir -p gpurun_out; export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs upgpt_amd/libupk_old.so = the library of commit b450d6c's csrc/ (UPK_LIB=... python -m upgpt_amd.build on that checkout)
 # same-box A/B: library before / after the loader's seek() refactor (commit b450d6c sources vs the tree)
 mkdir -p gpurun_out; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
